@@ -1,0 +1,103 @@
+"""Oracle: square-conv RecurrentNet forward in plain PyTorch fp32 (test
+infrastructure only).
+
+Restates /root/reference/Neural_Networks/Architectures/RecurrentNet.py:18-99
+with ``hex=False`` and the blocks it uses (blocks.py:12-41 BasicBlock,
+blocks.py:46-92 Reduce_ValueHead, blocks.py:130-170 Reduce_PolicyHead), plus the
+inference wrapper of Neural_Networks/Network_Manager.py:46-64.
+
+All convolutions are 3x3, stride 1, zero 'same' padding, bias-free.  Weights are
+a dict keyed by the reference's ``state_dict`` names, so a reference checkpoint
+(``model_state_dict``) loads unchanged.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def head_channels(width, out_channels, n_layers):
+    """Channel schedule shared by both heads: float steps truncated by int()
+    (blocks.py:56-66,144-153).  width 64 -> policy [64,32,1], value [64,48,32,16,1]."""
+    step = (out_channels - width) / n_layers
+    chans = [width]
+    prev = float(width)
+    for _ in range(n_layers):
+        prev = prev + step
+        chans.append(int(prev))
+    return chans
+
+
+def param_shapes(in_channels, policy_channels, width, num_blocks, recall=True):
+    """Ordered (name, shape) list; names as in the reference's state_dict."""
+    out = [("projection.0.weight", (width, in_channels, 3, 3))]
+    idx = 0
+    if recall:
+        out.append(("recur_module.0.weight", (width, width + in_channels, 3, 3)))
+        idx = 1
+    for b in range(num_blocks):
+        out.append((f"recur_module.{idx + b}.before_shortcut.0.weight", (width, width, 3, 3)))
+        out.append((f"recur_module.{idx + b}.before_shortcut.2.weight", (width, width, 3, 3)))
+    pc = head_channels(width, policy_channels, 2)
+    for i in range(2):
+        out.append((f"policy_head.layers.{2 * i}.weight", (pc[i + 1], pc[i], 3, 3)))
+    vc = head_channels(width, 1, 4)
+    for i in range(4):
+        out.append((f"value_head.layers.{2 * i}.weight", (vc[i + 1], vc[i], 3, 3)))
+    return out
+
+
+class RecurrentNetRef:
+    def __init__(self, weights, in_channels, policy_channels, width=64, num_blocks=2,
+                 recall=True, value_activation="tanh"):
+        self.w = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in weights.items()}
+        self.in_channels = in_channels
+        self.policy_channels = policy_channels
+        self.width = width
+        self.num_blocks = num_blocks
+        self.recall = recall
+        self.value_activation = value_activation
+        self.recurrent = True
+
+    def _conv(self, x, name):
+        return F.conv2d(x, self.w[name], None, 1, "same")
+
+    def forward(self, x, iters):
+        """RecurrentNet.py:82-99."""
+        x = torch.as_tensor(x, dtype=torch.float32)
+        thought = F.relu(self._conv(x, "projection.0.weight"))
+        base = 1 if self.recall else 0
+        for _ in range(iters):
+            if self.recall:
+                thought = torch.cat([thought, x], 1)           # RecurrentNet.py:91
+                thought = self._conv(thought, "recur_module.0.weight")   # no activation
+            for b in range(self.num_blocks):                     # blocks.py:37-41
+                pre = f"recur_module.{base + b}.before_shortcut."
+                y = F.relu(self._conv(thought, pre + "0.weight"))
+                y = self._conv(y, pre + "2.weight")
+                thought = F.relu(y + thought)
+        p = F.relu(self._conv(thought, "policy_head.layers.0.weight"))
+        p = self._conv(p, "policy_head.layers.2.weight")
+        act = torch.tanh if self.value_activation == "tanh" else F.relu
+        v = thought
+        for i in range(4):
+            v = self._conv(v, f"value_head.layers.{2 * i}.weight")
+            if i != 3:
+                v = act(v)
+        v = torch.tanh(v.mean(dim=(1, 2, 3)).reshape(-1, 1))     # blocks.py:82-84
+        return p, v
+
+    def inference(self, state, iters):
+        """Network_Manager.py:46-64 (eval mode, no_grad); numpy outputs.
+
+        Runs with one intra-op thread: the golden vectors were made that way
+        (the reference's batch-1 inference is fastest single-threaded, SURVEY.md
+        section 6) and oneDNN's conv result depends on the thread count in the
+        last bit."""
+        n = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            with torch.no_grad():
+                p, v = self.forward(state, iters)
+        finally:
+            torch.set_num_threads(n)
+        return p.numpy(), v.numpy()
