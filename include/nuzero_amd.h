@@ -1,0 +1,213 @@
+/*
+ * nuzero_amd.h -- C ABI of the MI355X self-play engine.
+ *
+ * The reference (guilherme439/NuZero) is pure Python and has no FFI; the
+ * boundary this library replaces is the Python contract between the trainer and
+ * the self-play worker.  Each entry point names the
+ * reference code whose work it takes over.  All paths are relative to the
+ * reference repository root.
+ *
+ * Conventions
+ *   - plain C symbols, opaque handle, int status (0 = NZ_OK), no exceptions;
+ *   - one engine per GPU, not thread-safe (one Gamer = one single-threaded
+ *     actor in the reference, Training/Gamer.py:17-37);
+ *   - "dev" pointers are device pointers owned by the caller (PyTorch-ROCm
+ *     tensors); "host" pointers are ordinary host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     work is enqueued on it and is NOT synchronised unless stated.
+ */
+#ifndef NUZERO_AMD_H
+#define NUZERO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nz_engine nz_engine;
+typedef struct nz_rng nz_rng;
+typedef int nz_status;
+
+enum {
+  NZ_OK = 0,
+  NZ_ERR_ARG = 1,        /* bad argument / unsupported configuration */
+  NZ_ERR_HIP = 2,        /* a HIP call failed; see nz_last_error */
+  NZ_ERR_STATE = 3,      /* call out of order (e.g. search before weights) */
+  NZ_ERR_OVERFLOW = 4    /* a device-side capacity check failed */
+};
+
+enum { NZ_GAME_TIC_TAC_TOE = 0 };
+enum { NZ_ACT_TANH = 0, NZ_ACT_RELU = 1 };
+
+/* Search hyper-parameters: exactly the keys the reference's Explorer reads
+ * from its search config (Configs/Search/Examples/documentation_search_config.yaml:1-47;
+ * Search/Explorer.py:48,74,79-80,105-106,122,202-205). */
+typedef struct nz_search_cfg {
+  int32_t mcts_simulations;
+  int32_t keep_subtree;                 /* must be 1 (Gamer.py:78-79) */
+  double pb_c_base;
+  double pb_c_init;
+  int32_t number_of_softmax_moves;
+  int32_t training;                     /* Explorer(search_config, training) */
+  double epsilon_softmax_exploration;
+  double epsilon_random_exploration;
+  double value_factor;
+  double root_exploration_fraction;
+  double root_dist_alpha;
+  double root_dist_beta;
+} nz_search_cfg;
+
+/* Game description (the duck-typed Game surface, Games/Game.py). */
+typedef struct nz_game_desc {
+  int32_t game;                         /* NZ_GAME_* */
+  int32_t negate_player;                /* Q is negated iff parent.to_play == this (Explorer.py:124) */
+} nz_game_desc;
+
+/* RecurrentNet(in_channels, policy_channels, num_filters, num_blocks, recall,
+ * policy_head="conv", value_head="reduce", value_activation, hex=False)
+ * (Neural_Networks/Architectures/RecurrentNet.py:18-79). */
+typedef struct nz_net_desc {
+  int32_t in_channels;
+  int32_t policy_channels;
+  int32_t width;
+  int32_t num_blocks;
+  int32_t recall;
+  int32_t value_activation;             /* NZ_ACT_* */
+} nz_net_desc;
+
+/* Fixed per-engine sizes, for sizing the caller's export buffers. */
+typedef struct nz_dims {
+  int32_t n_games;
+  int32_t num_actions;                  /* A */
+  int32_t max_moves;                    /* T */
+  int32_t state_channels, rows, cols;   /* C, H, W */
+  int32_t node_capacity;                /* tree arena nodes per game */
+} nz_dims;
+
+const char* nz_version(void);
+/* Message of the last failure on `e` (or of the last failed nz_engine_create when e == NULL). */
+const char* nz_last_error(const nz_engine* e);
+
+/* ---- engine life cycle ---------------------------------------------------
+ * Replaces: Gamer.__init__ (Training/Gamer.py:20-37), one per actor, and the
+ * per-game `game_class(*game_args)` / `Node(0)` set-up (Gamer.py:52,59). */
+nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game,
+                           int32_t n_games, int32_t device);
+void nz_engine_destroy(nz_engine* e);
+nz_status nz_engine_dims(const nz_engine* e, nz_dims* out);
+
+/* Hand the network to the engine.  Replaces `shared_storage.get` +
+ * `network_copy.check_devices()` (Gamer.py:40,61-62) and selects what
+ * Network_Manager.inference (Neural_Networks/Network_Manager.py:46-64) computes.
+ * `weights[i]` are float32 tensors in the reference's state_dict order and
+ * [C_out][C_in][3][3] layout (host or device memory); they are repacked for the
+ * MFMA kernel and copied, so the caller may free them afterwards. */
+nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const float* const* weights,
+                                int32_t n_tensors, int32_t recurrent_iterations);
+
+/* Test hook: evaluate leaves by table look-up instead of the network.
+ * table[code][0..8] = post-softmax probabilities, table[code][9] = value,
+ * code = sum(cell[a] * 3^a); 19683 rows, host or device memory.  Same meaning
+ * as a cache hit in Explorer.evaluate (Explorer.py:146-149). */
+nz_status nz_engine_set_table(nz_engine* e, const float* table, int32_t n_rows);
+
+/* New batch of games: every game back to the initial position with an
+ * unexpanded root (Gamer.py:52-59). */
+nz_status nz_engine_reset(nz_engine* e, void* stream);
+
+/* Children of each game's current root, 0 for an unexpanded root or a finished
+ * game: the number of gamma draws add_exploration_noise will take
+ * (Explorer.py:201-210).  dev int32[G]. */
+nz_status nz_engine_root_children(nz_engine* e, int32_t* n_children_dev, void* stream);
+
+/* One move for every live game: Explorer.run_mcts (Explorer.py:40-67:
+ * root noise, mcts_simulations x {select, evaluate/expand, backup},
+ * select_action) followed by game.step, store_search_statistics and re-rooting
+ * (Gamer.py:65-79).
+ *   noise_dev    double[G][A]: gamma draws for the root's children in child
+ *                order (first n_children entries of a row are used); may be
+ *                NULL when training == 0.
+ *   uniforms_dev double[G][3]: epsilon_softmax, epsilon_random and the uniform
+ *                np.random.choice consumes (Explorer.py:77-78,89,199); may be
+ *                NULL when training == 0. */
+nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev,
+                         void* stream);
+
+/* 1 for every game that is not yet terminal, else 0.  dev int32[G]. */
+nz_status nz_engine_alive(nz_engine* e, int32_t* alive_dev, void* stream);
+
+/* Number of games not yet terminal.  Synchronises `stream`. */
+nz_status nz_engine_live_games(nz_engine* e, int32_t* n_live_host, void* stream);
+
+/* Whole games with the engine's own host random streams: game g uses a private
+ * legacy MT19937 stream seeded base_seed + g, consumed in the reference's order
+ * (SURVEY.md appendix A rules 13-17).  Resets, then plays until every game is
+ * terminal (Gamer.play_game, Gamer.py:39-97, for G games).  Synchronises. */
+nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream);
+
+/* Results of the batch, the data ReplayBuffer.save_game reads from a game
+ * (Training/ReplayBuffer.py:24-36) plus the per-move statistics Gamer reports
+ * (Gamer.py:42-50,81-92).  Any pointer may be NULL.  T = max_moves.
+ *   states    float [G][T][C][H][W]  game.state_history (zeros past the end)
+ *   visits    int32 [G][T][A]        root child visit counts by action
+ *                                    (child_policy = visits / sum, tic_tac_toe.py:177-182)
+ *   actions   int32 [G][T]           chosen action, -1 past the end
+ *   lengths   int32 [G]              game.length
+ *   outcomes  int32 [G]              game.terminal_value
+ *   tree_size int32 [G][T]           root.visit_count after the search (Gamer.py:71)
+ *   n_children int32[G][T]           root.num_children()             (Gamer.py:72)
+ *   bias      double[G][T]           final_root_bias                 (Explorer.py:63)
+ */
+nz_status nz_engine_export(nz_engine* e, float* states, int32_t* visits, int32_t* actions,
+                           int32_t* lengths, int32_t* outcomes, int32_t* tree_size,
+                           int32_t* n_children, double* bias, void* stream);
+
+/* Parity trace of the root's children after each search, by action index:
+ * prior (after noise), value_sum; plus root value_sum.  dev double[G][T][A],
+ * double[G][T][A], double[G][T].  Any pointer may be NULL. */
+nz_status nz_engine_export_trace(nz_engine* e, double* child_prior, double* child_value_sum,
+                                 double* root_value_sum, void* stream);
+
+/* Work counters since the last reset, summed over games: simulations and
+ * node expansions (= network evaluations, Explorer.py:144-181).  Synchronises. */
+nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* expansions_host,
+                             void* stream);
+/* As above plus the select work done: out[0] simulations, out[1] expansions,
+ * out[2] internal nodes whose children were scored (descent levels), out[3]
+ * children scored.  Used to price the tree kernel's algorithmic bytes. */
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream);
+
+/* Algorithmic FLOPs of one network evaluation (one position): sum over convs of
+ * 2 * C_out * C_in * 49, i.e. only the taps that fall inside the 3x3 board. */
+nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host);
+
+/* ---- stand-alone operators (same kernels, callable by themselves) ---------
+ * Network_Manager.inference for a batch (Network_Manager.py:46-64):
+ * states float[B][C][3][3] -> logits float[B][P*9], value float[B]; and the
+ * softmax Explorer.evaluate applies (Explorer.py:159) -> probs float[B][P*9]
+ * (may be NULL). */
+nz_status nz_net_forward(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev,
+                         float* value_dev, float* probs_dev, void* stream);
+
+/* Timing of the engine's own kernels, measured with HIP events on the stream
+ * the kernels run on.  Enable, run, then read: total milliseconds and launch
+ * count per kernel class (0 = tree advance, 1 = network, 2 = move/noise/export). */
+nz_status nz_engine_profile(nz_engine* e, int32_t enable);
+nz_status nz_engine_profile_read(nz_engine* e, double* ms_host /*[3]*/, int64_t* launches_host /*[3]*/,
+                                 int64_t* net_positions_host);
+
+/* ---- host random streams (numpy legacy RandomState, MT19937) --------------
+ * Replaces the reference's use of the global np.random stream
+ * (Explorer.py:77-78,89,199,208). */
+nz_rng* nz_rng_create(uint32_t seed);
+void nz_rng_destroy(nz_rng* r);
+void nz_rng_seed(nz_rng* r, uint32_t seed);
+uint32_t nz_rng_u32(nz_rng* r);
+double nz_rng_double(nz_rng* r);                                  /* random_sample() */
+void nz_rng_gamma(nz_rng* r, double shape, double scale, int32_t n, double* out);  /* gamma(shape, scale, n) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NUZERO_AMD_H */

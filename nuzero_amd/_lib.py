@@ -1,0 +1,99 @@
+"""ctypes binding of include/nuzero_amd.h.
+
+The shared library is built in-tree by ``python -m nuzero_amd.build``.  There is
+no fallback: if it is missing, importing this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libnuzero_amd.so")
+
+NZ_OK, NZ_ERR_ARG, NZ_ERR_HIP, NZ_ERR_STATE, NZ_ERR_OVERFLOW = range(5)
+NZ_GAME_TIC_TAC_TOE = 0
+NZ_ACT_TANH, NZ_ACT_RELU = 0, 1
+
+
+class SearchCfg(Structure):
+    _fields_ = [("mcts_simulations", c_int32), ("keep_subtree", c_int32),
+                ("pb_c_base", c_double), ("pb_c_init", c_double),
+                ("number_of_softmax_moves", c_int32), ("training", c_int32),
+                ("epsilon_softmax_exploration", c_double), ("epsilon_random_exploration", c_double),
+                ("value_factor", c_double), ("root_exploration_fraction", c_double),
+                ("root_dist_alpha", c_double), ("root_dist_beta", c_double)]
+
+
+class GameDesc(Structure):
+    _fields_ = [("game", c_int32), ("negate_player", c_int32)]
+
+
+class NetDesc(Structure):
+    _fields_ = [("in_channels", c_int32), ("policy_channels", c_int32), ("width", c_int32),
+                ("num_blocks", c_int32), ("recall", c_int32), ("value_activation", c_int32)]
+
+
+class Dims(Structure):
+    _fields_ = [("n_games", c_int32), ("num_actions", c_int32), ("max_moves", c_int32),
+                ("state_channels", c_int32), ("rows", c_int32), ("cols", c_int32),
+                ("node_capacity", c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/nuzero_amd.h declares
+SIGNATURES = {
+    "nz_version": (c_char_p, []),
+    "nz_last_error": (c_char_p, [c_void_p]),
+    "nz_engine_create": (c_int32, [POINTER(c_void_p), POINTER(SearchCfg), POINTER(GameDesc), c_int32, c_int32]),
+    "nz_engine_destroy": (None, [c_void_p]),
+    "nz_engine_dims": (c_int32, [c_void_p, POINTER(Dims)]),
+    "nz_engine_set_weights": (c_int32, [c_void_p, POINTER(NetDesc), POINTER(c_void_p), c_int32, c_int32]),
+    "nz_engine_set_table": (c_int32, [c_void_p, c_void_p, c_int32]),
+    "nz_engine_reset": (c_int32, [c_void_p, c_void_p]),
+    "nz_engine_root_children": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_engine_alive": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_engine_move": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_engine_live_games": (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
+    "nz_engine_play": (c_int32, [c_void_p, c_uint64, c_void_p]),
+    "nz_engine_export": (c_int32, [c_void_p] + [c_void_p] * 8 + [c_void_p]),
+    "nz_engine_export_trace": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_engine_counters": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
+    "nz_engine_counters_ex": (c_int32, [c_void_p, POINTER(c_int64), c_void_p]),
+    "nz_engine_net_flops": (c_int32, [c_void_p, POINTER(c_double)]),
+    "nz_net_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_engine_profile": (c_int32, [c_void_p, c_int32]),
+    "nz_engine_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_int64)]),
+    "nz_rng_create": (c_void_p, [c_uint32]),
+    "nz_rng_destroy": (None, [c_void_p]),
+    "nz_rng_seed": (None, [c_void_p, c_uint32]),
+    "nz_rng_u32": (c_uint32, [c_void_p]),
+    "nz_rng_double": (c_double, [c_void_p]),
+    "nz_rng_gamma": (None, [c_void_p, c_double, c_double, c_int32, POINTER(c_double)]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m nuzero_amd.build` "
+            "(the engine has no CPU or PyTorch fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class NzError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"nuzero_amd error {code}: {message}")
+        self.code = code
+
+
+def check(status, handle=None):
+    if status != NZ_OK:
+        msg = lib.nz_last_error(handle)
+        raise NzError(status, msg.decode() if msg else "")

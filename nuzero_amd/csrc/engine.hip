@@ -1,0 +1,626 @@
+// Host side of the C ABI (include/nuzero_amd.h): buffer ownership, the per-move
+// launch sequence, weight packing for the MFMA kernel and the host random
+// streams' call order.  No compute happens here.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+using namespace nz;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct ProfileSpan {
+  hipEvent_t a, b;
+  int cls;
+};
+}  // namespace
+
+struct nz_engine {
+  nz_search_cfg cfg;
+  nz_game_desc game;
+  int device = 0;
+  int n_games = 0;
+  int cap = 0;
+  int tab_len = 0;
+  TreeParams tp;
+  std::vector<void*> allocs;
+  std::string error;
+  // network
+  bool have_net = false, have_table = false;
+  nz_net_desc net;
+  int iters = 0;
+  NetProgram prog_host;
+  NetProgram* prog_dev = nullptr;
+  float* weights_dev = nullptr;
+  float* table_dev = nullptr;
+  float* leaf_logits = nullptr;
+  float* leaf_value = nullptr;
+  double algorithmic_flops_per_position = 0.0;
+  // host staging for nz_engine_play
+  int32_t* h_children = nullptr;   // pinned [G]
+  int32_t* h_alive = nullptr;      // pinned [G]
+  double* h_noise = nullptr;       // pinned [G][A]
+  double* h_uniforms = nullptr;    // pinned [G][3]
+  double* d_noise = nullptr;
+  double* d_uniforms = nullptr;
+  std::vector<nz_rng*> rngs;
+  // profiling
+  bool profile = false;
+  std::vector<ProfileSpan> spans;
+  int64_t net_positions = 0;       // upper bound: positions offered to the network kernel
+};
+
+namespace {
+
+nz_status fail(nz_engine* e, nz_status code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (e) e->error = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define NZ_HIP(e, call)                                                                          \
+  do {                                                                                           \
+    hipError_t err__ = (call);                                                                   \
+    if (err__ != hipSuccess)                                                                     \
+      return fail((e), NZ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err__), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+nz_status dev_alloc(nz_engine* e, T** out, size_t count) {
+  void* p = nullptr;
+  NZ_HIP(e, hipMalloc(&p, count * sizeof(T)));
+  e->allocs.push_back(p);
+  *out = static_cast<T*>(p);
+  return NZ_OK;
+}
+
+struct Span {
+  nz_engine* e;
+  hipStream_t s;
+  ProfileSpan sp{};
+  bool on;
+  Span(nz_engine* e_, hipStream_t s_, int cls) : e(e_), s(s_), on(e_->profile) {
+    if (!on) return;
+    sp.cls = cls;
+    if (hipEventCreate(&sp.a) != hipSuccess || hipEventCreate(&sp.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(sp.a, s);
+  }
+  ~Span() {
+    if (!on) return;
+    (void)hipEventRecord(sp.b, s);
+    e->spans.push_back(sp);
+  }
+};
+
+int head_channel(int width, int out, int n_layers, int idx) {   // blocks.py:56-66,144-153
+  const double step = (double)(out - width) / n_layers;
+  double prev = width;
+  int c = width;
+  for (int i = 0; i < idx; ++i) {
+    prev += step;
+    c = (int)prev;
+  }
+  return c;
+}
+
+// Repack one conv's [Cout][Cin][3][3] weights into the per-lane order the MFMA
+// kernel reads (net.hip): main[tap][kgroup][ntile][lane][4], extra[tap][ntile][lane].
+void pack_conv(const float* w, int cout, int cin, int cin_main, std::vector<float>& out, NetLayer& ly) {
+  const int ntiles = (cout + 15) / 16;
+  const int kgroups = (cin_main + 15) / 16;
+  while (out.size() % 4) out.push_back(0.f);
+  ly.w_off = (int32_t)out.size();
+  ly.cin_main = kgroups * 16;
+  ly.kgroups = kgroups;
+  ly.cout = cout;
+  ly.ntiles = ntiles;
+  for (int t = 0; t < 9; ++t)
+    for (int kg = 0; kg < kgroups; ++kg)
+      for (int nt = 0; nt < ntiles; ++nt)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int co = nt * 16 + (lane & 15);
+            const int ci = kg * 16 + (lane >> 4) * 4 + j;
+            out.push_back(co < cout && ci < cin_main ? w[((size_t)co * cin + ci) * 9 + t] : 0.f);
+          }
+  ly.extra = cin > cin_main ? 1 : 0;
+  ly.wx_off = (int32_t)out.size();
+  if (ly.extra)
+    for (int t = 0; t < 9; ++t)
+      for (int nt = 0; nt < ntiles; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int co = nt * 16 + (lane & 15);
+          const int ci = cin_main + (lane >> 4);
+          out.push_back(co < cout && ci < cin ? w[((size_t)co * cin + ci) * 9 + t] : 0.f);
+        }
+}
+
+hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+nz_status check_device_flag(nz_engine* e, hipStream_t s) {
+  int32_t flag = 0;
+  NZ_HIP(e, hipMemcpyAsync(&flag, e->tp.error_flag, sizeof(flag), hipMemcpyDeviceToHost, s));
+  NZ_HIP(e, hipStreamSynchronize(s));
+  if (flag != 0)
+    return fail(e, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 = tree arena full, 2 = visit table too short, "
+                                    "4 = move finished before its search)", flag);
+  return NZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nz_version(void) { return "nuzero_amd 0.1 (gfx950)"; }
+
+const char* nz_last_error(const nz_engine* e) { return e ? e->error.c_str() : g_create_error.c_str(); }
+
+nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game, int32_t n_games,
+                           int32_t device) {
+  if (!out || !cfg || !game) return fail(nullptr, NZ_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (game->game != NZ_GAME_TIC_TAC_TOE) return fail(nullptr, NZ_ERR_ARG, "unsupported game %d", game->game);
+  if (n_games <= 0) return fail(nullptr, NZ_ERR_ARG, "n_games must be positive");
+  if (cfg->mcts_simulations <= 0) return fail(nullptr, NZ_ERR_ARG, "mcts_simulations must be positive");
+  if (!cfg->keep_subtree)
+    return fail(nullptr, NZ_ERR_ARG, "keep_subtree = False is not supported: the reference never resets the root "
+                                     "in that mode (Training/Gamer.py:78-79) and every shipped config sets True");
+  if (!(cfg->pb_c_base > 0)) return fail(nullptr, NZ_ERR_ARG, "pb_c_base must be positive");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(nullptr, NZ_ERR_HIP, "no HIP device available (the engine has no CPU fallback)");
+  if (device < 0 || device >= n_dev) return fail(nullptr, NZ_ERR_ARG, "device %d out of range", device);
+
+  nz_engine* e = new nz_engine;
+  e->cfg = *cfg;
+  e->game = *game;
+  e->device = device;
+  e->n_games = n_games;
+  // every expansion at move m adds at most 9 - m children: 1 + sims * (9 + 8 + ... + 1)
+  e->cap = 1 + cfg->mcts_simulations * 45;
+  e->tab_len = cfg->mcts_simulations * TTT_MAX_MOVES + 2;
+  nz_status st = NZ_OK;
+  auto bail = [&](nz_status s) {
+    g_create_error = e->error;
+    nz_engine_destroy(e);
+    return s;
+  };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(e, NZ_ERR_HIP, "hipSetDevice(%d) failed", device));
+
+  TreeParams& p = e->tp;
+  memset(&p, 0, sizeof(p));
+  const size_t G = n_games, N = G * (size_t)e->cap, GT = G * TTT_MAX_MOVES, GTA = GT * TTT_ACTIONS;
+#define A(ptr, n)                                        \
+  if ((st = dev_alloc(e, &(ptr), (n))) != NZ_OK) return bail(st)
+  A(p.visit, N); A(p.value_sum, N); A(p.prior, N); A(p.link, N);
+  A(p.board, G); A(p.length, G); A(p.alive, G); A(p.outcome, G); A(p.root, G); A(p.node_count, G);
+  A(p.sims_left, G); A(p.pending, G); A(p.leaf_board, G); A(p.path, G * MAX_PATH); A(p.path_len, G);
+  A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.n_root_children, G);
+  A(p.leaf_count, 2); A(p.leaf_boards, G); A(e->leaf_logits, G * TTT_ACTIONS); A(e->leaf_value, G);
+  A(p.error_flag, 1);
+  A(p.hist_board, GT); A(p.hist_action, GT); A(p.hist_visits, GTA); A(p.hist_tree_size, GT);
+  A(p.hist_children, GT); A(p.hist_bias, GT); A(p.hist_prior, GTA); A(p.hist_value_sum, GTA);
+  A(p.hist_root_value_sum, GT);
+  double *bias_tab = nullptr, *sqrt_tab = nullptr;
+  A(bias_tab, e->tab_len); A(sqrt_tab, e->tab_len);
+  A(e->d_noise, G * TTT_ACTIONS); A(e->d_uniforms, G * 3);
+  A(e->prog_dev, 1);
+#undef A
+  p.leaf_logits = e->leaf_logits;
+  p.leaf_value = e->leaf_value;
+  p.cap = e->cap;
+  p.n_games = n_games;
+  p.table = nullptr;
+  p.tab_len = e->tab_len;
+  p.sims = cfg->mcts_simulations;
+  p.negate_player = game->negate_player;
+  p.value_factor = cfg->value_factor;
+  p.frac = cfg->root_exploration_fraction;
+  p.one_minus_frac = 1.0 - cfg->root_exploration_fraction;
+  p.training = cfg->training;
+  p.softmax_moves = cfg->number_of_softmax_moves;
+  p.eps_softmax = cfg->epsilon_softmax_exploration;
+  p.eps_random = cfg->epsilon_random_exploration;
+
+  // Explorer.calculate_exploration_bias / calculate_ucb_factor (Explorer.py:103-112):
+  // log() and sqrt() of the parent visit count, from the host libm
+  std::vector<double> hb(e->tab_len), hs(e->tab_len);
+  for (int n = 0; n < e->tab_len; ++n) {
+    hb[n] = std::log(((double)n + cfg->pb_c_base + 1.0) / cfg->pb_c_base) + cfg->pb_c_init;
+    hs[n] = std::sqrt((double)n);
+  }
+  if (hipMemcpy(bias_tab, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(sqrt_tab, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    return bail(fail(e, NZ_ERR_HIP, "table upload failed"));
+  p.bias_tab = bias_tab;
+  p.sqrt_tab = sqrt_tab;
+
+  if (hipHostMalloc((void**)&e->h_children, G * sizeof(int32_t)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_alive, G * sizeof(int32_t)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_noise, G * TTT_ACTIONS * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_uniforms, G * 3 * sizeof(double)) != hipSuccess)
+    return bail(fail(e, NZ_ERR_HIP, "pinned host allocation failed"));
+  memset(e->h_noise, 0, G * TTT_ACTIONS * sizeof(double));
+  memset(e->h_uniforms, 0, G * 3 * sizeof(double));
+
+  launch_reset(p, nullptr);
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, NZ_ERR_HIP, "reset kernel failed"));
+  *out = e;
+  return NZ_OK;
+}
+
+void nz_engine_destroy(nz_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->weights_dev) (void)hipFree(e->weights_dev);
+  if (e->table_dev) (void)hipFree(e->table_dev);
+  if (e->h_children) (void)hipHostFree(e->h_children);
+  if (e->h_alive) (void)hipHostFree(e->h_alive);
+  if (e->h_noise) (void)hipHostFree(e->h_noise);
+  if (e->h_uniforms) (void)hipHostFree(e->h_uniforms);
+  for (nz_rng* r : e->rngs) nz_rng_destroy(r);
+  for (auto& sp : e->spans) {
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  delete e;
+}
+
+nz_status nz_engine_dims(const nz_engine* e, nz_dims* out) {
+  if (!e || !out) return NZ_ERR_ARG;
+  out->n_games = e->n_games;
+  out->num_actions = TTT_ACTIONS;
+  out->max_moves = TTT_MAX_MOVES;
+  out->state_channels = 2;
+  out->rows = 3;
+  out->cols = 3;
+  out->node_capacity = e->cap;
+  return NZ_OK;
+}
+
+nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const float* const* weights,
+                                int32_t n_tensors, int32_t recurrent_iterations) {
+  if (!e || !net || !weights) return NZ_ERR_ARG;
+  if (net->in_channels != 2 || net->policy_channels != 1)
+    return fail(e, NZ_ERR_ARG, "Tic-Tac-Toe nets take 2 input planes and 1 policy plane");
+  if (net->width <= 0 || net->width > 64 || net->width % 4 != 0)
+    return fail(e, NZ_ERR_ARG, "width must be a multiple of 4 in (0, 64]");
+  if (net->num_blocks < 0 || recurrent_iterations < 0) return fail(e, NZ_ERR_ARG, "negative block/iteration count");
+  const int expect = 1 + (net->recall ? 1 : 0) + 2 * net->num_blocks + 2 + 4;
+  if (n_tensors != expect) return fail(e, NZ_ERR_ARG, "expected %d weight tensors, got %d", expect, n_tensors);
+  const int per_iter = (net->recall ? 1 : 0) + 2 * net->num_blocks;
+  if (1 + recurrent_iterations * per_iter + 6 > NET_MAX_LAYERS)
+    return fail(e, NZ_ERR_ARG, "too many layers for one fused launch (%d iterations)", recurrent_iterations);
+  NZ_HIP(e, hipSetDevice(e->device));
+
+  const int W = net->width, IN = net->in_channels;
+  // tensor shapes in state_dict order (RecurrentNet.py:18-79)
+  struct Shape { int cout, cin; };
+  std::vector<Shape> shapes;
+  shapes.push_back({W, IN});
+  if (net->recall) shapes.push_back({W, W + IN});
+  for (int b = 0; b < 2 * net->num_blocks; ++b) shapes.push_back({W, W});
+  for (int i = 0; i < 2; ++i)
+    shapes.push_back({head_channel(W, net->policy_channels, 2, i + 1), head_channel(W, net->policy_channels, 2, i)});
+  for (int i = 0; i < 4; ++i) shapes.push_back({head_channel(W, 1, 4, i + 1), head_channel(W, 1, 4, i)});
+
+  std::vector<std::vector<float>> host(n_tensors);
+  for (int i = 0; i < n_tensors; ++i) {
+    host[i].resize((size_t)shapes[i].cout * shapes[i].cin * 9);
+    NZ_HIP(e, hipMemcpy(host[i].data(), weights[i], host[i].size() * sizeof(float), hipMemcpyDefault));
+  }
+
+  std::vector<float> packed;
+  std::vector<NetLayer> tensors(n_tensors);
+  for (int i = 0; i < n_tensors; ++i) {
+    const bool with_planes = (i == 0) || (net->recall && i == 1);
+    const int cin_main = with_planes ? shapes[i].cin - IN : shapes[i].cin;
+    pack_conv(host[i].data(), shapes[i].cout, shapes[i].cin, cin_main, packed, tensors[i]);
+  }
+
+  // layer program: buffer 0/1 ping-pong, `cur` holds the running thought
+  NetProgram& pg = e->prog_host;
+  memset(&pg, 0, sizeof(pg));
+  int n = 0, cur = 0;
+  double flops = 0.0;   // in-bounds taps only: 2 * Cout * Cin * 49 per conv
+  auto emit = [&](int tensor, int src, int dst, int res, int act) {
+    NetLayer ly = tensors[tensor];
+    ly.src = src; ly.dst = dst; ly.res = res; ly.act = act;
+    pg.layers[n++] = ly;
+    flops += 2.0 * shapes[tensor].cout * shapes[tensor].cin * 49.0;
+  };
+  emit(0, 0, cur, -1, 1);                                  // projection + ReLU
+  const int first_block = net->recall ? 2 : 1;
+  for (int it = 0; it < recurrent_iterations; ++it) {
+    if (net->recall) { emit(1, cur, cur ^ 1, -1, 0); cur ^= 1; }      // cat([thought, x]) conv, no activation
+    for (int b = 0; b < net->num_blocks; ++b) {                        // relu(conv2(relu(conv1(t))) + t)
+      emit(first_block + 2 * b, cur, cur ^ 1, -1, 1);
+      emit(first_block + 2 * b + 1, cur ^ 1, cur, cur, 1);
+    }
+  }
+  const int ph = first_block + 2 * net->num_blocks, vh = ph + 2;
+  const int vact = net->value_activation == NZ_ACT_RELU ? 1 : 2;
+  emit(ph, cur, cur ^ 1, -1, 1);
+  emit(ph + 1, cur ^ 1, 2, -1, 0);
+  emit(vh, cur, cur ^ 1, -1, vact);
+  emit(vh + 1, cur ^ 1, cur, -1, vact);
+  emit(vh + 2, cur, cur ^ 1, -1, vact);
+  emit(vh + 3, cur ^ 1, 3, -1, 0);
+  pg.n_layers = n;
+  e->algorithmic_flops_per_position = flops;
+
+  if (e->weights_dev) { (void)hipFree(e->weights_dev); e->weights_dev = nullptr; }
+  NZ_HIP(e, hipMalloc((void**)&e->weights_dev, packed.size() * sizeof(float)));
+  NZ_HIP(e, hipMemcpy(e->weights_dev, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+  NZ_HIP(e, hipMemcpy(e->prog_dev, &pg, sizeof(pg), hipMemcpyHostToDevice));
+  e->net = *net;
+  e->iters = recurrent_iterations;
+  e->have_net = true;
+  e->have_table = false;
+  e->tp.table = nullptr;
+  return NZ_OK;
+}
+
+nz_status nz_engine_set_table(nz_engine* e, const float* table, int32_t n_rows) {
+  if (!e || !table) return NZ_ERR_ARG;
+  if (n_rows != TTT_TABLE_ROWS) return fail(e, NZ_ERR_ARG, "table must have %d rows", TTT_TABLE_ROWS);
+  NZ_HIP(e, hipSetDevice(e->device));
+  if (!e->table_dev) NZ_HIP(e, hipMalloc((void**)&e->table_dev, (size_t)TTT_TABLE_ROWS * 10 * sizeof(float)));
+  NZ_HIP(e, hipMemcpy(e->table_dev, table, (size_t)TTT_TABLE_ROWS * 10 * sizeof(float), hipMemcpyDefault));
+  e->tp.table = e->table_dev;
+  e->have_table = true;
+  return NZ_OK;
+}
+
+nz_status nz_engine_reset(nz_engine* e, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  NZ_HIP(e, hipSetDevice(e->device));
+  Span sp(e, as_stream(stream), 2);
+  launch_reset(e->tp, as_stream(stream));
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_root_children(nz_engine* e, int32_t* n_children_dev, void* stream) {
+  if (!e || !n_children_dev) return NZ_ERR_ARG;
+  NZ_HIP(e, hipMemcpyAsync(n_children_dev, e->tp.n_root_children, e->n_games * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, as_stream(stream)));
+  return NZ_OK;
+}
+
+nz_status nz_engine_alive(nz_engine* e, int32_t* alive_dev, void* stream) {
+  if (!e || !alive_dev) return NZ_ERR_ARG;
+  NZ_HIP(e, hipMemcpyAsync(alive_dev, e->tp.alive, e->n_games * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                           as_stream(stream)));
+  return NZ_OK;
+}
+
+nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  if (e->cfg.training && (!noise_dev || !uniforms_dev))
+    return fail(e, NZ_ERR_ARG, "training search needs noise and uniforms");
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  const TreeParams& p = e->tp;
+  if (e->cfg.training) {
+    Span sp(e, s, 2);
+    launch_noise(p, noise_dev, s);
+  }
+  if (p.table != nullptr) {
+    // table evaluator: nothing leaves the tree kernel, one launch does the whole search
+    Span sp(e, s, 0);
+    launch_advance(p, 0, s);
+  } else {
+    const int sims = e->cfg.mcts_simulations;
+    for (int it = 0; it <= sims; ++it) {
+      {
+        Span sp(e, s, 0);
+        launch_advance(p, it, s);
+      }
+      if (it == sims) break;
+      {
+        Span sp(e, s, 1);
+        launch_net(e->prog_dev, e->prog_host.n_layers, e->weights_dev, p.leaf_boards, nullptr,
+                   p.leaf_count + (it & 1), e->n_games, e->leaf_logits, e->leaf_value, nullptr, s);
+      }
+    }
+  }
+  {
+    Span sp(e, s, 2);
+    launch_finish_move(p, uniforms_dev, s);
+  }
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_live_games(nz_engine* e, int32_t* n_live_host, void* stream) {
+  if (!e || !n_live_host) return NZ_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  NZ_HIP(e, hipMemcpyAsync(e->h_alive, e->tp.alive, e->n_games * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  NZ_HIP(e, hipStreamSynchronize(s));
+  int n = 0;
+  for (int g = 0; g < e->n_games; ++g) n += e->h_alive[g] != 0;
+  *n_live_host = n;
+  return check_device_flag(e, s);
+}
+
+nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  const int G = e->n_games;
+  const nz_search_cfg& c = e->cfg;
+  if (c.training) {
+    if ((int)e->rngs.size() != G) {
+      for (nz_rng* r : e->rngs) nz_rng_destroy(r);
+      e->rngs.assign(G, nullptr);
+      for (int g = 0; g < G; ++g) e->rngs[g] = nz_rng_create(0);
+    }
+    for (int g = 0; g < G; ++g) nz_rng_seed(e->rngs[g], (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu));
+  }
+  nz_status st = nz_engine_reset(e, stream);
+  if (st != NZ_OK) return st;
+  for (int move = 0; move < TTT_MAX_MOVES; ++move) {
+    NZ_HIP(e, hipMemcpyAsync(e->h_children, e->tp.n_root_children, G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NZ_HIP(e, hipMemcpyAsync(e->h_alive, e->tp.alive, G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NZ_HIP(e, hipStreamSynchronize(s));
+    int live = 0;
+    for (int g = 0; g < G; ++g) live += e->h_alive[g] != 0;
+    if (live == 0) break;
+    if (c.training) {
+      // the reference's draw order within a move (SURVEY.md appendix A rule 13):
+      // gamma x n_root_children, then random() x 2 unless this is a softmax move,
+      // then at most one more random() inside np.random.choice
+      for (int g = 0; g < G; ++g) {
+        if (!e->h_alive[g]) continue;
+        nz_rng* r = e->rngs[g];
+        nz_rng_gamma(r, c.root_dist_alpha, c.root_dist_beta, e->h_children[g], e->h_noise + (size_t)g * TTT_ACTIONS);
+        double u1 = 0.0, u2 = 0.0, u3 = 0.0;
+        bool choice = false;
+        if (move < c.number_of_softmax_moves) {
+          choice = true;
+        } else {
+          u1 = nz_rng_double(r);
+          u2 = nz_rng_double(r);
+          choice = (u1 < c.epsilon_softmax_exploration) || (u2 < c.epsilon_random_exploration);
+        }
+        if (choice) u3 = nz_rng_double(r);
+        e->h_uniforms[g * 3 + 0] = u1;
+        e->h_uniforms[g * 3 + 1] = u2;
+        e->h_uniforms[g * 3 + 2] = u3;
+      }
+      NZ_HIP(e, hipMemcpyAsync(e->d_noise, e->h_noise, (size_t)G * TTT_ACTIONS * sizeof(double), hipMemcpyHostToDevice, s));
+      NZ_HIP(e, hipMemcpyAsync(e->d_uniforms, e->h_uniforms, (size_t)G * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    st = nz_engine_move(e, e->d_noise, e->d_uniforms, stream);
+    if (st != NZ_OK) return st;
+  }
+  return check_device_flag(e, s);
+}
+
+nz_status nz_engine_export(nz_engine* e, float* states, int32_t* visits, int32_t* actions, int32_t* lengths,
+                           int32_t* outcomes, int32_t* tree_size, int32_t* n_children, double* bias, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  Span sp(e, s, 2);
+  if (states) launch_export_states(e->tp, states, s);
+  if (visits || actions || tree_size || n_children || bias)
+    launch_export_visits(e->tp, visits, actions, tree_size, n_children, bias, s);
+  if (lengths)
+    NZ_HIP(e, hipMemcpyAsync(lengths, e->tp.length, e->n_games * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (outcomes)
+    NZ_HIP(e, hipMemcpyAsync(outcomes, e->tp.outcome, e->n_games * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_export_trace(nz_engine* e, double* child_prior, double* child_value_sum, double* root_value_sum,
+                                 void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const size_t GT = (size_t)e->n_games * TTT_MAX_MOVES;
+  if (child_prior)
+    NZ_HIP(e, hipMemcpyAsync(child_prior, e->tp.hist_prior, GT * TTT_ACTIONS * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (child_value_sum)
+    NZ_HIP(e, hipMemcpyAsync(child_value_sum, e->tp.hist_value_sum, GT * TTT_ACTIONS * sizeof(double), hipMemcpyDeviceToDevice, s));
+  if (root_value_sum)
+    NZ_HIP(e, hipMemcpyAsync(root_value_sum, e->tp.hist_root_value_sum, GT * sizeof(double), hipMemcpyDeviceToDevice, s));
+  return NZ_OK;
+}
+
+nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* expansions_host, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  std::vector<int32_t> a(e->n_games), b(e->n_games);
+  NZ_HIP(e, hipMemcpyAsync(a.data(), e->tp.sim_count, a.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  NZ_HIP(e, hipMemcpyAsync(b.data(), e->tp.exp_count, b.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  NZ_HIP(e, hipStreamSynchronize(s));
+  int64_t sa = 0, sb = 0;
+  for (int g = 0; g < e->n_games; ++g) { sa += a[g]; sb += b[g]; }
+  if (simulations_host) *simulations_host = sa;
+  if (expansions_host) *expansions_host = sb;
+  return NZ_OK;
+}
+
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream) {
+  if (!e || !out4_host) return NZ_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  const int32_t* src[4] = {e->tp.sim_count, e->tp.exp_count, e->tp.sel_nodes, e->tp.sel_children};
+  std::vector<int32_t> h(e->n_games);
+  for (int i = 0; i < 4; ++i) {
+    NZ_HIP(e, hipMemcpyAsync(h.data(), src[i], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NZ_HIP(e, hipStreamSynchronize(s));
+    int64_t sum = 0;
+    for (int32_t v : h) sum += v;
+    out4_host[i] = sum;
+  }
+  return NZ_OK;
+}
+
+nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host) {
+  if (!e || !flops_host) return NZ_ERR_ARG;
+  *flops_host = e->algorithmic_flops_per_position;
+  return NZ_OK;
+}
+
+nz_status nz_net_forward(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev, float* value_dev,
+                         float* probs_dev, void* stream) {
+  if (!e || !states_dev || !logits_dev || !value_dev) return NZ_ERR_ARG;
+  if (!e->have_net) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  if (batch <= 0) return NZ_OK;
+  NZ_HIP(e, hipSetDevice(e->device));
+  Span sp(e, as_stream(stream), 1);
+  launch_net(e->prog_dev, e->prog_host.n_layers, e->weights_dev, nullptr, states_dev, nullptr, batch, logits_dev,
+             value_dev, probs_dev, as_stream(stream));
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_profile(nz_engine* e, int32_t enable) {
+  if (!e) return NZ_ERR_ARG;
+  for (auto& sp : e->spans) {
+    (void)hipEventDestroy(sp.a);
+    (void)hipEventDestroy(sp.b);
+  }
+  e->spans.clear();
+  e->profile = enable != 0;
+  return NZ_OK;
+}
+
+nz_status nz_engine_profile_read(nz_engine* e, double* ms_host, int64_t* launches_host, int64_t* net_positions_host) {
+  if (!e) return NZ_ERR_ARG;
+  NZ_HIP(e, hipSetDevice(e->device));
+  NZ_HIP(e, hipDeviceSynchronize());
+  double ms[3] = {0, 0, 0};
+  int64_t n[3] = {0, 0, 0};
+  for (auto& sp : e->spans) {
+    float t = 0.f;
+    NZ_HIP(e, hipEventElapsedTime(&t, sp.a, sp.b));
+    ms[sp.cls] += t;
+    n[sp.cls] += 1;
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (ms_host) ms_host[i] = ms[i];
+    if (launches_host) launches_host[i] = n[i];
+  }
+  if (net_positions_host) *net_positions_host = 0;
+  return NZ_OK;
+}
+
+}  // extern "C"

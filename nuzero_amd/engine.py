@@ -1,0 +1,231 @@
+"""Python face of the C ABI: owns one nz_engine and the PyTorch-ROCm tensors it
+writes into.  PyTorch is used for device memory and streams only."""
+import ctypes
+from ctypes import byref, c_double, c_int32, c_int64, c_void_p
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+from .search_config import to_struct
+
+
+def _ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SelfPlayEngine:
+    """G concurrent Tic-Tac-Toe self-play games on one GPU.
+
+    ``search_config`` is the reference's nested dict; ``training`` is the second
+    argument of the reference's ``Explorer(search_config, training)``.
+    """
+
+    def __init__(self, search_config, n_games, training=True, device=0, negate_player=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("nuzero_amd needs a ROCm GPU; there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.search_config = search_config
+        self.training = bool(training)
+        cfg = to_struct(search_config, training)
+        game = _lib.GameDesc(game=_lib.NZ_GAME_TIC_TAC_TOE, negate_player=negate_player)
+        self._h = c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_create(byref(self._h), byref(cfg), byref(game), int(n_games), int(device)))
+        d = _lib.Dims()
+        check(lib.nz_engine_dims(self._h, byref(d)), self._h)
+        self.n_games, self.num_actions, self.max_moves = d.n_games, d.num_actions, d.max_moves
+        self.state_shape = (d.state_channels, d.rows, d.cols)
+        self.node_capacity = d.node_capacity
+        self.net_spec = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.nz_engine_destroy(self._h)
+            self._h = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- network ---------------------------------------------------------------
+    def set_weights(self, weights, width=64, num_blocks=2, recall=True, value_activation="tanh",
+                    recurrent_iterations=2, in_channels=2, policy_channels=1):
+        """``weights``: name -> array/tensor with the reference's state_dict keys
+        (RecurrentNet, hex=False), in state_dict order."""
+        tensors = []
+        for v in weights.values():
+            t = v.detach() if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
+            tensors.append(t.to(torch.float32).contiguous())
+        ptrs = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        nd = _lib.NetDesc(in_channels=in_channels, policy_channels=policy_channels, width=width,
+                          num_blocks=num_blocks, recall=int(recall),
+                          value_activation=_lib.NZ_ACT_RELU if value_activation == "relu" else _lib.NZ_ACT_TANH)
+        for t in tensors:
+            if t.is_cuda:
+                torch.cuda.synchronize(t.device)
+        check(lib.nz_engine_set_weights(self._h, byref(nd), ptrs, len(tensors), int(recurrent_iterations)), self._h)
+        self.net_spec = dict(width=width, num_blocks=num_blocks, recall=recall, iters=recurrent_iterations)
+
+    def set_table(self, table):
+        """Test hook: [19683, 10] float32 table evaluator (9 probs + value)."""
+        t = np.ascontiguousarray(table, dtype=np.float32)
+        check(lib.nz_engine_set_table(self._h, t.ctypes.data_as(c_void_p), int(t.shape[0])), self._h)
+
+    def net_flops_per_position(self):
+        v = c_double(0)
+        check(lib.nz_engine_net_flops(self._h, byref(v)), self._h)
+        return v.value
+
+    def net_forward(self, states, want_probs=True):
+        """Network_Manager.inference for a float32 [B, 2, 3, 3] batch on the GPU.
+        Returns (logits [B, 9], value [B], probs [B, 9] or None)."""
+        x = torch.as_tensor(states, dtype=torch.float32).to(self.device).contiguous()
+        b = x.shape[0]
+        logits = torch.empty((b, 9), dtype=torch.float32, device=self.device)
+        value = torch.empty((b,), dtype=torch.float32, device=self.device)
+        probs = torch.empty((b, 9), dtype=torch.float32, device=self.device) if want_probs else None
+        with torch.cuda.device(self.device):
+            check(lib.nz_net_forward(self._h, _ptr(x), b, _ptr(logits), _ptr(value), _ptr(probs), _stream()), self._h)
+        return logits, value, probs
+
+    # ---- stepping --------------------------------------------------------------
+    def reset(self):
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_reset(self._h, _stream()), self._h)
+
+    def root_children(self):
+        out = torch.empty((self.n_games,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_root_children(self._h, _ptr(out), _stream()), self._h)
+        return out
+
+    def move(self, noise=None, uniforms=None):
+        """One move for every live game.  noise: float64 [G, A]; uniforms: float64 [G, 3]."""
+        if noise is not None:
+            noise = torch.as_tensor(noise, dtype=torch.float64).to(self.device).contiguous()
+            uniforms = torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_move(self._h, _ptr(noise), _ptr(uniforms), _stream()), self._h)
+
+    def live_games(self):
+        n = c_int32(0)
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_live_games(self._h, byref(n), _stream()), self._h)
+        return n.value
+
+    def play(self, base_seed=0):
+        """Reset and play every game to the end with the engine's own host
+        random streams (game g <- RandomState(base_seed + g))."""
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_play(self._h, int(base_seed), _stream()), self._h)
+
+    def play_with_numpy_rng(self, seeds):
+        """Same as play(), but the randomness is drawn here from numpy
+        RandomState objects in the reference's call order -- the slow,
+        ground-truth path the parity tests use."""
+        ex = self.search_config["Exploration"]
+        rngs = [np.random.RandomState(int(s)) for s in seeds]
+        assert len(rngs) == self.n_games
+        self.reset()
+        for move in range(self.max_moves):
+            if self.live_games() == 0:
+                break
+            if not self.training:
+                self.move()
+                continue
+            nchild = self.root_children().cpu().numpy()
+            alive = self.alive().cpu().numpy()
+            noise = np.zeros((self.n_games, self.num_actions), np.float64)
+            uni = np.zeros((self.n_games, 3), np.float64)
+            for g, rs in enumerate(rngs):
+                if alive[g] == 0:
+                    continue
+                n = int(nchild[g])
+                noise[g, :n] = rs.gamma(ex["root_dist_alpha"], ex["root_dist_beta"], n)
+                if move < ex["number_of_softmax_moves"]:
+                    uni[g, 2] = rs.random_sample()
+                else:
+                    u1, u2 = rs.random_sample(), rs.random_sample()
+                    uni[g, 0], uni[g, 1] = u1, u2
+                    if u1 < ex["epsilon_softmax_exploration"] or u2 < ex["epsilon_random_exploration"]:
+                        uni[g, 2] = rs.random_sample()
+            self.move(noise, uni)
+        assert self.live_games() == 0
+
+    def alive(self):
+        out = torch.empty((self.n_games,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_alive(self._h, _ptr(out), _stream()), self._h)
+        return out
+
+    # ---- results ---------------------------------------------------------------
+    def export(self, states=True, trace=False):
+        G, T, A = self.n_games, self.max_moves, self.num_actions
+        dev = self.device
+        out = {
+            "states": torch.empty((G, T) + self.state_shape, dtype=torch.float32, device=dev) if states else None,
+            "visits": torch.empty((G, T, A), dtype=torch.int32, device=dev),
+            "actions": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "lengths": torch.empty((G,), dtype=torch.int32, device=dev),
+            "outcomes": torch.empty((G,), dtype=torch.int32, device=dev),
+            "tree_size": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "n_children": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "bias": torch.empty((G, T), dtype=torch.float64, device=dev),
+        }
+        with torch.cuda.device(dev):
+            check(lib.nz_engine_export(self._h, _ptr(out["states"]), _ptr(out["visits"]), _ptr(out["actions"]),
+                                       _ptr(out["lengths"]), _ptr(out["outcomes"]), _ptr(out["tree_size"]),
+                                       _ptr(out["n_children"]), _ptr(out["bias"]), _stream()), self._h)
+            if trace:
+                out["child_prior"] = torch.empty((G, T, A), dtype=torch.float64, device=dev)
+                out["child_value_sum"] = torch.empty((G, T, A), dtype=torch.float64, device=dev)
+                out["root_value_sum"] = torch.empty((G, T), dtype=torch.float64, device=dev)
+                check(lib.nz_engine_export_trace(self._h, _ptr(out["child_prior"]), _ptr(out["child_value_sum"]),
+                                                 _ptr(out["root_value_sum"]), _stream()), self._h)
+        return {k: (v.cpu().numpy() if v is not None else None) for k, v in out.items()}
+
+    def export_device(self):
+        """The replay payload as device tensors (for the multi-GPU gather)."""
+        G, T, A = self.n_games, self.max_moves, self.num_actions
+        dev = self.device
+        out = {
+            "states": torch.empty((G, T) + self.state_shape, dtype=torch.float32, device=dev),
+            "visits": torch.empty((G, T, A), dtype=torch.int32, device=dev),
+            "actions": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "lengths": torch.empty((G,), dtype=torch.int32, device=dev),
+            "outcomes": torch.empty((G,), dtype=torch.int32, device=dev),
+            "tree_size": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "n_children": torch.empty((G, T), dtype=torch.int32, device=dev),
+            "bias": torch.empty((G, T), dtype=torch.float64, device=dev),
+        }
+        with torch.cuda.device(dev):
+            check(lib.nz_engine_export(self._h, _ptr(out["states"]), _ptr(out["visits"]), _ptr(out["actions"]),
+                                       _ptr(out["lengths"]), _ptr(out["outcomes"]), _ptr(out["tree_size"]),
+                                       _ptr(out["n_children"]), _ptr(out["bias"]), _stream()), self._h)
+        return out
+
+    def counters(self):
+        out = (c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_counters_ex(self._h, out, _stream()), self._h)
+        return {"simulations": out[0], "expansions": out[1], "select_nodes": out[2], "select_children": out[3]}
+
+    # ---- kernel timing -----------------------------------------------------------
+    def profile(self, enable=True):
+        check(lib.nz_engine_profile(self._h, int(enable)), self._h)
+
+    def profile_read(self):
+        ms = (c_double * 3)()
+        n = (c_int64 * 3)()
+        pos = c_int64(0)
+        check(lib.nz_engine_profile_read(self._h, ms, n, byref(pos)), self._h)
+        names = ("tree_advance", "network", "move_misc")
+        return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
