@@ -5,6 +5,13 @@ no fallback: if it is missing, importing this module raises.
 """
 import ctypes
 import os
+
+# PyTorch-ROCm ships its own libamdhip64.so.7; the engine library is linked against
+# the same SONAME.  Importing torch first makes the process use ONE HIP runtime (torch's)
+# whatever the import order of the caller -- two runtimes in one process do not see
+# each other's devices or streams.
+import torch  # noqa: F401
+
 from ctypes import POINTER, Structure, c_char_p, c_double, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
