@@ -146,6 +146,14 @@ nz_status nz_engine_live_games(nz_engine* e, int32_t* n_live_host, void* stream)
  * terminal (Gamer.play_game, Gamer.py:39-97, for G games).  Synchronises. */
 nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream);
 
+/* Same games, same results, by the lock-step route: one kernel sequence per move
+ * with a host round trip in between (the route nz_engine_move exposes).
+ * nz_engine_play runs the persistent self-play kernel instead and falls back to
+ * this route for the rare game whose pre-drawn randomness does not fit. */
+nz_status nz_engine_play_lockstep(nz_engine* e, uint64_t base_seed, void* stream);
+/* Games nz_engine_play had to replay by the lock-step route since creation. */
+nz_status nz_engine_desync_count(const nz_engine* e, int64_t* count_host);
+
 /* Results of the batch, the data ReplayBuffer.save_game reads from a game
  * (Training/ReplayBuffer.py:24-36) plus the per-move statistics Gamer reports
  * (Gamer.py:42-50,81-92).  Any pointer may be NULL.  T = max_moves.

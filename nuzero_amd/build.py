@@ -17,11 +17,12 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 UNITS = [
     ("tree.hip", ["-ffp-contract=off"]),
-    ("net.hip", []),
+    ("net.hip", ["-ffp-contract=off"]),
+    ("selfplay.hip", ["-ffp-contract=off"]),
     ("engine.hip", ["-ffp-contract=off"]),
     ("rng_host.cpp", ["-ffp-contract=off"]),
 ]
-HEADERS = ["engine.h", os.path.join("..", "..", "include", "nuzero_amd.h")]
+HEADERS = ["engine.h", "tree_dev.hpp", "net_dev.hpp", os.path.join("..", "..", "include", "nuzero_amd.h")]
 
 
 def _stale(target, sources):

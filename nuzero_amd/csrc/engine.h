@@ -50,6 +50,7 @@ struct TreeParams {
   int32_t* sel_nodes;     // descent levels (internal nodes scored)
   int32_t* sel_children;  // children scored
   int32_t* n_root_children;
+  int32_t* desync;        // 1: the host's pre-drawn randomness did not fit this game (selfplay.hip)
   // leaf queue feeding the network kernel
   int32_t* leaf_count;    // [2], ping-pong by iteration parity
   uint32_t* leaf_boards;  // [G]
@@ -88,6 +89,9 @@ void launch_finish_move(const TreeParams& p, const double* uniforms, hipStream_t
 void launch_export_states(const TreeParams& p, float* states, hipStream_t s);
 void launch_export_visits(const TreeParams& p, int32_t* visits, int32_t* actions, int32_t* tree_size,
                           int32_t* n_children, double* bias, hipStream_t s);
+
+void launch_selfplay(const TreeParams& p, const struct NetProgram* prog_dev, int n_layers, const float* weights,
+                     const double* noise, const double* uniforms, hipStream_t s);
 
 // ---- network ----------------------------------------------------------------
 struct NetLayer {

@@ -5,7 +5,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -50,6 +52,15 @@ struct nz_engine {
   double* d_noise = nullptr;
   double* d_uniforms = nullptr;
   std::vector<nz_rng*> rngs;
+  // persistent-kernel path: whole-game randomness, [G][T][A] and [G][T][3]
+  double* h_game_noise = nullptr;     // pinned
+  double* h_game_uniforms = nullptr;  // pinned
+  double* d_game_noise = nullptr;
+  double* d_game_uniforms = nullptr;
+  int32_t* h_desync = nullptr;        // pinned [G]
+  bool borrowed_net = false;          // fallback engine: network buffers belong to the parent
+  nz_engine* fallback = nullptr;
+  int64_t desync_total = 0;
   // profiling
   bool profile = false;
   std::vector<ProfileSpan> spans;
@@ -206,7 +217,7 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
   A(p.visit, N); A(p.value_sum, N); A(p.prior, N); A(p.link, N);
   A(p.board, G); A(p.length, G); A(p.alive, G); A(p.outcome, G); A(p.root, G); A(p.node_count, G);
   A(p.sims_left, G); A(p.pending, G); A(p.leaf_board, G); A(p.path, G * MAX_PATH); A(p.path_len, G);
-  A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.n_root_children, G);
+  A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.desync, G); A(p.n_root_children, G);
   A(p.leaf_count, 2); A(p.leaf_boards, G); A(e->leaf_logits, G * TTT_ACTIONS); A(e->leaf_value, G);
   A(p.error_flag, 1);
   A(p.hist_board, GT); A(p.hist_action, GT); A(p.hist_visits, GTA); A(p.hist_tree_size, GT);
@@ -215,6 +226,7 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
   double *bias_tab = nullptr, *sqrt_tab = nullptr;
   A(bias_tab, e->tab_len); A(sqrt_tab, e->tab_len);
   A(e->d_noise, G * TTT_ACTIONS); A(e->d_uniforms, G * 3);
+  A(e->d_game_noise, GTA); A(e->d_game_uniforms, GT * 3);
   A(e->prog_dev, 1);
 #undef A
   p.leaf_logits = e->leaf_logits;
@@ -249,10 +261,15 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
   if (hipHostMalloc((void**)&e->h_children, G * sizeof(int32_t)) != hipSuccess ||
       hipHostMalloc((void**)&e->h_alive, G * sizeof(int32_t)) != hipSuccess ||
       hipHostMalloc((void**)&e->h_noise, G * TTT_ACTIONS * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void**)&e->h_uniforms, G * 3 * sizeof(double)) != hipSuccess)
+      hipHostMalloc((void**)&e->h_uniforms, G * 3 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_game_noise, GTA * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_game_uniforms, GT * 3 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_desync, G * sizeof(int32_t)) != hipSuccess)
     return bail(fail(e, NZ_ERR_HIP, "pinned host allocation failed"));
   memset(e->h_noise, 0, G * TTT_ACTIONS * sizeof(double));
   memset(e->h_uniforms, 0, G * 3 * sizeof(double));
+  memset(e->h_game_noise, 0, GTA * sizeof(double));
+  memset(e->h_game_uniforms, 0, GT * 3 * sizeof(double));
 
   launch_reset(p, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, NZ_ERR_HIP, "reset kernel failed"));
@@ -265,8 +282,12 @@ void nz_engine_destroy(nz_engine* e) {
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
   for (void* p : e->allocs) (void)hipFree(p);
-  if (e->weights_dev) (void)hipFree(e->weights_dev);
-  if (e->table_dev) (void)hipFree(e->table_dev);
+  if (e->fallback) nz_engine_destroy(e->fallback);
+  if (e->weights_dev && !e->borrowed_net) (void)hipFree(e->weights_dev);
+  if (e->table_dev && !e->borrowed_net) (void)hipFree(e->table_dev);
+  if (e->h_game_noise) (void)hipHostFree(e->h_game_noise);
+  if (e->h_game_uniforms) (void)hipHostFree(e->h_game_uniforms);
+  if (e->h_desync) (void)hipHostFree(e->h_desync);
   if (e->h_children) (void)hipHostFree(e->h_children);
   if (e->h_alive) (void)hipHostFree(e->h_alive);
   if (e->h_noise) (void)hipHostFree(e->h_noise);
@@ -458,20 +479,42 @@ nz_status nz_engine_live_games(nz_engine* e, int32_t* n_live_host, void* stream)
   return check_device_flag(e, s);
 }
 
-nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
-  if (!e) return NZ_ERR_ARG;
-  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
-  NZ_HIP(e, hipSetDevice(e->device));
+// The per-move draws of one game in the reference's order (SURVEY.md appendix A
+// rule 13): gamma x n_children, then random() x 2 unless this is a softmax
+// move, then at most one more random() inside np.random.choice.
+static void draw_move(nz_rng* r, const nz_search_cfg& c, int move, int n_children, double* noise9, double* uni3) {
+  nz_rng_gamma(r, c.root_dist_alpha, c.root_dist_beta, n_children, noise9);
+  double u1 = 0.0, u2 = 0.0, u3 = 0.0;
+  bool choice;
+  if (move < c.number_of_softmax_moves) {
+    choice = true;
+  } else {
+    u1 = nz_rng_double(r);
+    u2 = nz_rng_double(r);
+    choice = (u1 < c.epsilon_softmax_exploration) || (u2 < c.epsilon_random_exploration);
+  }
+  if (choice) u3 = nz_rng_double(r);
+  uni3[0] = u1;
+  uni3[1] = u2;
+  uni3[2] = u3;
+}
+
+static void ensure_rngs(nz_engine* e) {
+  if ((int)e->rngs.size() == e->n_games) return;
+  for (nz_rng* r : e->rngs) nz_rng_destroy(r);
+  e->rngs.assign(e->n_games, nullptr);
+  for (int g = 0; g < e->n_games; ++g) e->rngs[g] = nz_rng_create(0);
+}
+
+// Lock-step play: one host round trip per move to learn each root's child count
+// before drawing.  `seeds[g]` seeds game g's stream.
+static nz_status play_lockstep(nz_engine* e, const uint32_t* seeds, void* stream) {
   hipStream_t s = as_stream(stream);
   const int G = e->n_games;
   const nz_search_cfg& c = e->cfg;
   if (c.training) {
-    if ((int)e->rngs.size() != G) {
-      for (nz_rng* r : e->rngs) nz_rng_destroy(r);
-      e->rngs.assign(G, nullptr);
-      for (int g = 0; g < G; ++g) e->rngs[g] = nz_rng_create(0);
-    }
-    for (int g = 0; g < G; ++g) nz_rng_seed(e->rngs[g], (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu));
+    ensure_rngs(e);
+    for (int g = 0; g < G; ++g) nz_rng_seed(e->rngs[g], seeds[g]);
   }
   nz_status st = nz_engine_reset(e, stream);
   if (st != NZ_OK) return st;
@@ -483,27 +526,9 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
     for (int g = 0; g < G; ++g) live += e->h_alive[g] != 0;
     if (live == 0) break;
     if (c.training) {
-      // the reference's draw order within a move (SURVEY.md appendix A rule 13):
-      // gamma x n_root_children, then random() x 2 unless this is a softmax move,
-      // then at most one more random() inside np.random.choice
-      for (int g = 0; g < G; ++g) {
-        if (!e->h_alive[g]) continue;
-        nz_rng* r = e->rngs[g];
-        nz_rng_gamma(r, c.root_dist_alpha, c.root_dist_beta, e->h_children[g], e->h_noise + (size_t)g * TTT_ACTIONS);
-        double u1 = 0.0, u2 = 0.0, u3 = 0.0;
-        bool choice = false;
-        if (move < c.number_of_softmax_moves) {
-          choice = true;
-        } else {
-          u1 = nz_rng_double(r);
-          u2 = nz_rng_double(r);
-          choice = (u1 < c.epsilon_softmax_exploration) || (u2 < c.epsilon_random_exploration);
-        }
-        if (choice) u3 = nz_rng_double(r);
-        e->h_uniforms[g * 3 + 0] = u1;
-        e->h_uniforms[g * 3 + 1] = u2;
-        e->h_uniforms[g * 3 + 2] = u3;
-      }
+      for (int g = 0; g < G; ++g)
+        if (e->h_alive[g])
+          draw_move(e->rngs[g], c, move, e->h_children[g], e->h_noise + (size_t)g * TTT_ACTIONS, e->h_uniforms + g * 3);
       NZ_HIP(e, hipMemcpyAsync(e->d_noise, e->h_noise, (size_t)G * TTT_ACTIONS * sizeof(double), hipMemcpyHostToDevice, s));
       NZ_HIP(e, hipMemcpyAsync(e->d_uniforms, e->h_uniforms, (size_t)G * 3 * sizeof(double), hipMemcpyHostToDevice, s));
     }
@@ -511,6 +536,125 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
     if (st != NZ_OK) return st;
   }
   return check_device_flag(e, s);
+}
+
+nz_status nz_engine_play_lockstep(nz_engine* e, uint64_t base_seed, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  NZ_HIP(e, hipSetDevice(e->device));
+  std::vector<uint32_t> seeds(e->n_games);
+  for (int g = 0; g < e->n_games; ++g) seeds[g] = (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu);
+  return play_lockstep(e, seeds.data(), stream);
+}
+
+// Replay the games the persistent kernel flagged (their pre-drawn randomness did
+// not fit) on a small lock-step engine and copy their records back.
+static nz_status replay_desynced(nz_engine* e, const std::vector<int>& games, uint64_t base_seed, void* stream) {
+  hipStream_t s = as_stream(stream);
+  const int n = (int)games.size();
+  if (e->fallback && e->fallback->n_games < n) {
+    nz_engine_destroy(e->fallback);
+    e->fallback = nullptr;
+  }
+  if (!e->fallback) {
+    nz_engine* f = nullptr;
+    nz_status st = nz_engine_create(&f, &e->cfg, &e->game, std::max(n, 16), e->device);
+    if (st != NZ_OK) return fail(e, st, "fallback engine: %s", nz_last_error(nullptr));
+    f->borrowed_net = true;
+    e->fallback = f;
+  }
+  nz_engine* f = e->fallback;
+  f->weights_dev = e->weights_dev;
+  f->table_dev = e->table_dev;
+  f->tp.table = e->tp.table;
+  f->have_net = e->have_net;
+  f->have_table = e->have_table;
+  f->prog_host = e->prog_host;
+  NZ_HIP(e, hipMemcpy(f->prog_dev, &e->prog_host, sizeof(NetProgram), hipMemcpyHostToDevice));
+  std::vector<uint32_t> seeds(f->n_games, 0u);
+  for (int i = 0; i < n; ++i) seeds[i] = (uint32_t)((base_seed + (uint64_t)games[i]) & 0xffffffffu);
+  nz_status st = play_lockstep(f, seeds.data(), stream);
+  if (st != NZ_OK) return fail(e, st, "fallback replay: %s", f->error.c_str());
+  const TreeParams &a = f->tp, &b = e->tp;
+  for (int i = 0; i < n; ++i) {
+    const size_t g = games[i];
+#define ROW(field, per_game)                                                                               \
+  NZ_HIP(e, hipMemcpyAsync(b.field + g * (per_game), a.field + (size_t)i * (per_game),                     \
+                           (per_game) * sizeof(*a.field), hipMemcpyDeviceToDevice, s))
+    ROW(hist_board, TTT_MAX_MOVES); ROW(hist_action, TTT_MAX_MOVES); ROW(hist_tree_size, TTT_MAX_MOVES);
+    ROW(hist_children, TTT_MAX_MOVES); ROW(hist_bias, TTT_MAX_MOVES); ROW(hist_root_value_sum, TTT_MAX_MOVES);
+    ROW(hist_visits, TTT_MAX_MOVES * TTT_ACTIONS); ROW(hist_prior, TTT_MAX_MOVES * TTT_ACTIONS);
+    ROW(hist_value_sum, TTT_MAX_MOVES * TTT_ACTIONS);
+    ROW(length, 1); ROW(outcome, 1); ROW(board, 1);
+    ROW(sim_count, 1); ROW(exp_count, 1); ROW(sel_nodes, 1); ROW(sel_children, 1);
+#undef ROW
+  }
+  NZ_HIP(e, hipStreamSynchronize(s));
+  return NZ_OK;
+}
+
+nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  const int G = e->n_games;
+  const nz_search_cfg& c = e->cfg;
+
+  nz_status st = nz_engine_reset(e, stream);
+  if (st != NZ_OK) return st;
+  if (c.training) {
+    // whole-game draws, assuming the root of move m >= 1 has 9 - m children (selfplay.hip)
+    ensure_rngs(e);
+    const int n_threads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+    auto work = [&](int t) {
+      for (int g = t; g < G; g += n_threads) {
+        nz_rng* r = e->rngs[g];
+        nz_rng_seed(r, (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu));
+        for (int m = 0; m < TTT_MAX_MOVES; ++m)
+          draw_move(r, c, m, m == 0 ? 0 : TTT_ACTIONS - m,
+                    e->h_game_noise + ((size_t)g * TTT_MAX_MOVES + m) * TTT_ACTIONS,
+                    e->h_game_uniforms + ((size_t)g * TTT_MAX_MOVES + m) * 3);
+      }
+    };
+    if (G < 256 || n_threads == 1) {
+      for (int t = 0; t < n_threads; ++t) work(t);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+      for (auto& th : pool) th.join();
+    }
+    const size_t GT = (size_t)G * TTT_MAX_MOVES;
+    NZ_HIP(e, hipMemcpyAsync(e->d_game_noise, e->h_game_noise, GT * TTT_ACTIONS * sizeof(double), hipMemcpyHostToDevice, s));
+    NZ_HIP(e, hipMemcpyAsync(e->d_game_uniforms, e->h_game_uniforms, GT * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+  }
+  {
+    Span sp(e, s, 0);
+    launch_selfplay(e->tp, e->prog_dev, e->prog_host.n_layers, e->weights_dev,
+                    c.training ? e->d_game_noise : nullptr, c.training ? e->d_game_uniforms : nullptr, s);
+  }
+  NZ_HIP(e, hipGetLastError());
+  st = check_device_flag(e, s);
+  if (st != NZ_OK) return st;
+  if (c.training) {
+    NZ_HIP(e, hipMemcpyAsync(e->h_desync, e->tp.desync, G * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    NZ_HIP(e, hipStreamSynchronize(s));
+    std::vector<int> bad;
+    for (int g = 0; g < G; ++g)
+      if (e->h_desync[g]) bad.push_back(g);
+    if (!bad.empty()) {
+      e->desync_total += (int64_t)bad.size();
+      st = replay_desynced(e, bad, base_seed, stream);
+      if (st != NZ_OK) return st;
+    }
+  }
+  return NZ_OK;
+}
+
+nz_status nz_engine_desync_count(const nz_engine* e, int64_t* count_host) {
+  if (!e || !count_host) return NZ_ERR_ARG;
+  *count_host = e->desync_total;
+  return NZ_OK;
 }
 
 nz_status nz_engine_export(nz_engine* e, float* states, int32_t* visits, int32_t* actions, int32_t* lengths,

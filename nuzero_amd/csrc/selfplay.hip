@@ -1,0 +1,182 @@
+// Persistent self-play kernel (gfx950): one workgroup owns 16 games for their
+// whole life and alternates, with no kernel boundary and no inter-workgroup
+// traffic, between
+//   tree phase  4 waves x 4 games, one 16-lane row per game: finish the pending
+//               expansion, simulate until the next leaf that needs the network,
+//               and, when a move's simulations are used up, pick the action,
+//               step the game, re-root and mix the next root's noise;
+//   net phase   the fused RecurrentNet forward for the 16 pending leaves on
+//               FP32 MFMA (net_dev.hpp), inputs and outputs in LDS.
+// A game's tree is only ever touched by its own row, so games progress through
+// their moves independently of each other: the whole
+// select -> inference -> expand -> backup -> move cycle (Training/Gamer.py:64-79
+// around Search/Explorer.py:40-67) stays on the GPU.  With 4096 games the grid is
+// 256 workgroups, one per CU.
+//
+// Randomness.  The reference's draws per move (gamma x n_root_children, two
+// uniforms, at most one more inside np.random.choice; SURVEY.md appendix A rule
+// 13) come from a per-game host stream.  The host pre-draws every move's values
+// assuming the root of move m >= 1 is expanded with 9 - m children (move 0's
+// root is never expanded).  The kernel checks the assumption at every re-root;
+// a game that violates it (its chosen child was never visited) is flagged
+// `desync`, stops, and is replayed by the lock-step path, which asks the device
+// for the child count before drawing.
+#include "net_dev.hpp"
+#include "tree_dev.hpp"
+
+namespace nz {
+namespace {
+
+__global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, const NetProgram* __restrict__ prog,
+                                                               int n_layers, const float* __restrict__ W,
+                                                               const double* __restrict__ noise,      // [G][T][A]
+                                                               const double* __restrict__ uniforms) { // [G][T][3]
+  __shared__ __attribute__((aligned(16))) float lds[2 * ACT_FLOATS + INP_FLOATS + POS * TTT_ACTIONS + POS];
+  float* const inp = lds + 2 * ACT_FLOATS;
+  float* const out_logits = inp + INP_FLOATS;          // [16][9]
+  float* const out_value = out_logits + POS * TTT_ACTIONS;
+
+  const int tid = threadIdx.x;
+  const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
+  const int sub = tid & (LANES_PER_GAME - 1);
+  const int g = blockIdx.x * POS + slot;
+
+  // per-game state, identical on the 16 lanes of a row (except my_node)
+  bool alive = g < p.n_games;
+  const Arena t = arena_of(p, alive ? g : 0);
+  int root = 0, node_count = 1, sims_left = p.sims, move = 0;
+  uint32_t board = 0u;
+  int n_sim = 0, n_exp = 0, n_lvl = 0, n_kid = 0;
+  bool pending = false;
+  int my_node = 0, path_len = 0, leaf = 0;
+  uint32_t leaf_sb = 0u, leaf_meta = 0u;
+  int outcome = 0;
+
+  for (;;) {
+    // ------------------------------ tree phase ---------------------------------
+    if (alive) {
+      if (pending) {
+        const float logit = sub < 9 ? out_logits[slot * TTT_ACTIONS + sub] : 0.0f;
+        const float prob = row_softmax9(logit, sub);
+        const double value = (double)out_value[slot];
+        node_count = expand_row(p, t, leaf, leaf_meta, leaf_sb, prob, sub, node_count);
+        backup_row(t, my_node, path_len, value, sub);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        --sims_left;
+        ++n_sim;
+        ++n_exp;
+        pending = false;
+      }
+      while (alive && !pending) {
+        if (sims_left == 0) {
+          // ---- the move is searched: act, step, re-root (Gamer.py:71-79) ----------
+          int chosen = -1, new_root = root, term = 0, new_children = 0;
+          uint32_t new_board = board;
+          if (sub == 0) {
+            const MoveResult r = finish_move_one(p, t, g, root, board, move,
+                                                 uniforms ? uniforms + ((size_t)g * TTT_MAX_MOVES + move) * 3 : nullptr);
+            chosen = r.chosen; new_root = r.new_root; term = r.term; new_children = r.new_children;
+            new_board = r.new_board;
+          }
+          chosen = row_geti(chosen, 0);
+          new_root = row_geti(new_root, 0);
+          term = row_geti(term, 0);
+          new_children = row_geti(new_children, 0);
+          new_board = (uint32_t)row_geti((int)new_board, 0);
+          if (chosen < 0) { alive = false; break; }        // error flag already raised
+          board = new_board;
+          root = new_root;
+          ++move;
+          sims_left = p.sims;
+          if (term != 0) {
+            alive = false;
+            outcome = term_value(term);
+            break;
+          }
+          if (p.training) {
+            if (new_children != TTT_ACTIONS - move) {       // the host's draw-count assumption failed
+              if (sub == 0) p.desync[g] = 1;
+              alive = false;
+              break;
+            }
+            noise_row(p, t, root, noise + ((size_t)g * TTT_MAX_MOVES + move) * TTT_ACTIONS, sub);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          }
+          continue;
+        }
+        const Descent d = descend_row(p, t, root, board, sub, my_node);
+        n_lvl += d.levels;
+        n_kid += d.children;
+        const int term = ttt_terminal(d.sb);
+        if (term != 0) {
+          if (sub == 0)
+            t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
+          backup_row(t, my_node, d.path_len, (double)term_value(term), sub);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          --sims_left;
+          ++n_sim;
+          continue;
+        }
+        if (p.table != nullptr) {
+          const float* row = p.table + (size_t)ttt_code(d.sb) * 10;
+          const float prob = sub < 9 ? row[sub] : 0.0f;
+          const double value = (double)row[9];
+          node_count = expand_row(p, t, d.node, d.lk.y, d.sb, prob, sub, node_count);
+          backup_row(t, my_node, d.path_len, value, sub);
+          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          --sims_left;
+          ++n_sim;
+          ++n_exp;
+          continue;
+        }
+        // leaf needs the network
+        pending = true;
+        leaf = d.node;
+        leaf_meta = d.lk.y;
+        leaf_sb = d.sb;
+        path_len = d.path_len;
+      }
+    }
+    // this row's input planes: inp[cell][slot][4] = (P1 stone, P2 stone, 0, 0)
+    if (sub < CELLS) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pending) {
+        v.x = (float)((leaf_sb >> sub) & 1u);
+        v.y = (float)((leaf_sb >> (16 + sub)) & 1u);
+      }
+      *reinterpret_cast<float4*>(inp + (sub * POS + slot) * 4) = v;
+    }
+    if (!__syncthreads_or(pending ? 1 : 0)) break;
+
+    // ------------------------------ net phase ----------------------------------
+    net_tile(prog, n_layers, W, lds, inp, 1, POS, out_logits, out_value);
+    // net_tile ends with a barrier: outputs are visible to every row
+  }
+
+  if (g < p.n_games && sub == 0) {
+    p.board[g] = board;
+    p.length[g] = move;
+    p.alive[g] = 0;
+    p.outcome[g] = outcome;
+    p.root[g] = root;
+    p.node_count[g] = node_count;
+    p.sims_left[g] = sims_left;
+    p.pending[g] = -1;
+    p.n_root_children[g] = 0;
+    p.sim_count[g] = n_sim;
+    p.exp_count[g] = n_exp;
+    p.sel_nodes[g] = n_lvl;
+    p.sel_children[g] = n_kid;
+  }
+}
+
+}  // namespace
+
+void launch_selfplay(const TreeParams& p, const NetProgram* prog_dev, int n_layers, const float* weights,
+                     const double* noise, const double* uniforms, hipStream_t s) {
+  const int blocks = (p.n_games + POS - 1) / POS;
+  hipLaunchKernelGGL(selfplay_kernel, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights, noise,
+                     uniforms);
+}
+
+}  // namespace nz

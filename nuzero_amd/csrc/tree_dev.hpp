@@ -1,0 +1,360 @@
+// Device-side building blocks of the tree search, shared by the lock-step
+// kernels (tree.hip) and the persistent self-play kernel (selfplay.hip).
+// One 16-lane DPP row owns one game tree.
+//
+// Reference semantics restated here (paths relative to the reference repo):
+//   select   Search/Explorer.py:99-130  (PUCT score, ties -> larger action)
+//   expand   Search/Explorer.py:137-181 (mask, renormalise, children ascending)
+//   backup   Search/Explorer.py:132-135 (same value added along the path)
+//   noise    Search/Explorer.py:201-210
+//   action   Search/Explorer.py:70-97,183-199
+//   move     Training/Gamer.py:64-79
+//   rules    Games/Tic_Tac_Toe/tic_tac_toe.py:121-133,161-167,198-262
+//
+// Exactness: the reference does its tree arithmetic in IEEE double, one
+// operation at a time.  Every translation unit that includes this header is
+// compiled with -ffp-contract=off so no multiply-add is fused, log() and sqrt()
+// of the parent count come from tables the host fills with glibc's libm (what
+// CPython's math.log/sqrt call), and sums follow numpy's pairwise order.  Given
+// the same leaf evaluations the visit counts are bit-identical to the
+// reference's.
+//
+// Storage: structure-of-arrays per game arena; a node's children are contiguous
+// in ascending action order, so lane j of the row reads child j with one
+// coalesced access per array.
+#pragma once
+#include "engine.h"
+
+namespace nz {
+
+// ---- Tic-Tac-Toe on bitboards ------------------------------------------------
+__device__ __forceinline__ bool ttt_line(uint32_t m) {
+  return (m & 0007u) == 0007u || (m & 0070u) == 0070u || (m & 0700u) == 0700u ||
+         (m & 0111u) == 0111u || (m & 0222u) == 0222u || (m & 0444u) == 0444u ||
+         (m & 0421u) == 0421u || (m & 0124u) == 0124u;
+}
+__device__ __forceinline__ uint32_t ttt_p1(uint32_t b) { return b & 0x1ffu; }
+__device__ __forceinline__ uint32_t ttt_p2(uint32_t b) { return (b >> 16) & 0x1ffu; }
+__device__ __forceinline__ int ttt_length(uint32_t b) { return __popc(ttt_p1(b) | ttt_p2(b)); }
+__device__ __forceinline__ uint32_t ttt_empty(uint32_t b) { return ~(ttt_p1(b) | ttt_p2(b)) & 0x1ffu; }
+// player to move: (length % 2) + 1            (tic_tac_toe.py:165)
+__device__ __forceinline__ int ttt_player(uint32_t b) { return (ttt_length(b) & 1) + 1; }
+__device__ __forceinline__ uint32_t ttt_step(uint32_t b, int action) {
+  return b | ((1u << action) << (ttt_player(b) == 1 ? 0 : 16));
+}
+// 0 = not terminal, 1 = draw, 2 = player one won (+1), 3 = player two won (-1)
+__device__ __forceinline__ int ttt_terminal(uint32_t b) {
+  if (ttt_line(ttt_p1(b))) return 2;
+  if (ttt_line(ttt_p2(b))) return 3;
+  return ttt_length(b) == 9 ? 1 : 0;
+}
+__device__ __forceinline__ int term_value(int code) { return code == 2 ? 1 : (code == 3 ? -1 : 0); }
+__device__ __forceinline__ int ttt_code(uint32_t b) {   // sum cell[a] * 3^a
+  int code = 0;
+#pragma unroll
+  for (int a = 8; a >= 0; --a)
+    code = code * 3 + (int)((b >> a) & 1u) + 2 * (int)((b >> (16 + a)) & 1u);
+  return code;
+}
+
+// ---- row (16-lane) helpers ---------------------------------------------------
+__device__ __forceinline__ double row_get(double v, int lane) { return __shfl(v, lane, LANES_PER_GAME); }
+__device__ __forceinline__ float row_getf(float v, int lane) { return __shfl(v, lane, LANES_PER_GAME); }
+__device__ __forceinline__ int row_geti(int v, int lane) { return __shfl(v, lane, LANES_PER_GAME); }
+
+// numpy's pairwise sum for n = 9: eight running sums, then the tail
+// (checked against np.sum in tests/test_rng_host.py::test_pairwise_order)
+__device__ __forceinline__ double sum9(double v) {
+  const double a0 = row_get(v, 0), a1 = row_get(v, 1), a2 = row_get(v, 2), a3 = row_get(v, 3);
+  const double a4 = row_get(v, 4), a5 = row_get(v, 5), a6 = row_get(v, 6), a7 = row_get(v, 7);
+  const double a8 = row_get(v, 8);
+  double r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  return r + a8;
+}
+__device__ __forceinline__ float sum9f(float v) {
+  const float a0 = row_getf(v, 0), a1 = row_getf(v, 1), a2 = row_getf(v, 2), a3 = row_getf(v, 3);
+  const float a4 = row_getf(v, 4), a5 = row_getf(v, 5), a6 = row_getf(v, 6), a7 = row_getf(v, 7);
+  const float a8 = row_getf(v, 8);
+  float r = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  return r + a8;
+}
+
+// scipy.special.softmax over the nine logits of a row, float32
+// (Explorer.py:159: exp(x - max) / sum, numpy's summation order)
+__device__ __forceinline__ float row_softmax9(float logit, int sub) {
+  float m = sub < 9 ? logit : -INFINITY;
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1) m = fmaxf(m, __shfl_xor(m, w, LANES_PER_GAME));
+  const float e = sub < 9 ? expf(logit - m) : 0.0f;
+  const float s = sum9f(e);
+  return e / s;
+}
+
+struct Arena {
+  int32_t* visit;
+  double* value_sum;
+  double* prior;
+  uint2* link;
+};
+__device__ __forceinline__ Arena arena_of(const TreeParams& p, int g) {
+  const size_t off = (size_t)g * (size_t)p.cap;
+  return Arena{p.visit + off, p.value_sum + off, p.prior + off, p.link + off};
+}
+__device__ __forceinline__ void arena_reset(const Arena& t) {   // Node(0), Gamer.py:59
+  t.visit[0] = 0;
+  t.value_sum[0] = 0.0;
+  t.prior[0] = 0.0;
+  t.link[0] = make_uint2(0u, pack_meta(0u, 0u, TO_PLAY_UNSET, 0u));
+}
+
+// Explorer.evaluate's expansion (Explorer.py:165-179).  `prob` is this lane's
+// post-softmax float32 probability for action `sub`.  Returns the new node count.
+__device__ __forceinline__ int expand_row(const TreeParams& p, const Arena& t, int leaf, uint32_t leaf_meta,
+                                          uint32_t sb, float prob, int sub, int node_count) {
+  const uint32_t empty = ttt_empty(sb);
+  const bool legal = sub < 9 && ((empty >> sub) & 1u);
+  const double mask = legal ? 1.0 : 0.0;
+  double pd = sub < 9 ? (double)prob * mask : 0.0;
+  double total = sum9(pd);
+  if (total == 0.0) {                       // network put no mass on legal moves
+    pd = pd + mask;
+    total = sum9(pd);
+  }
+  const int k = __popc(empty);
+  const int base = node_count;
+  if (base + k > p.cap) {
+    if (sub == 0) atomicOr(p.error_flag, 1);
+    return node_count;
+  }
+  if (legal) {
+    const int c = base + __popc(empty & ((1u << sub) - 1u));
+    t.visit[c] = 0;
+    t.value_sum[c] = 0.0;
+    t.prior[c] = pd / total;
+    t.link[c] = make_uint2(0u, pack_meta(0u, (uint32_t)sub, TO_PLAY_UNSET, 0u));
+  }
+  if (sub == 0)
+    t.link[leaf] = make_uint2((uint32_t)base,
+                              pack_meta((uint32_t)k, meta_action(leaf_meta), (uint32_t)ttt_player(sb), 0u));
+  return node_count + k;
+}
+
+// Explorer.backpropagate (Explorer.py:132-135): lane i owns path node i.
+__device__ __forceinline__ void backup_row(const Arena& t, int my_node, int path_len, double value, int sub) {
+  if (sub < path_len) {
+    t.visit[my_node] += 1;
+    t.value_sum[my_node] = t.value_sum[my_node] + value;
+  }
+}
+
+// One descent from `root` (Explorer.py:51-58).  On return `node`/`lk` is the
+// leaf and its link word, `sb` the scratch position there, `path_len` the
+// number of nodes on the path and lane i's `my_node` is path node i.
+struct Descent {
+  int node;
+  uint2 lk;
+  uint32_t sb;
+  int path_len;
+  int levels, children;   // work done, for the byte accounting
+};
+__device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena& t, int root, uint32_t board,
+                                               int sub, int& my_node) {
+  Descent d;
+  d.node = root;
+  d.sb = board;
+  d.path_len = 1;
+  d.levels = 0;
+  d.children = 0;
+  if (sub == 0) my_node = root;
+  d.lk = t.link[root];
+  while (meta_children(d.lk.y) != 0u) {
+    const int k = (int)meta_children(d.lk.y);
+    const int base = (int)d.lk.x;
+    ++d.levels;
+    d.children += k;
+    const int n_parent = t.visit[d.node];
+    if (n_parent >= p.tab_len) {
+      if (sub == 0) atomicOr(p.error_flag, 2);
+      break;
+    }
+    const double sq = p.sqrt_tab[n_parent];
+    const double cb = p.bias_tab[n_parent];
+    const bool negate = (int)meta_to_play(d.lk.y) == p.negate_player;
+    double score = -INFINITY;
+    int action = -1;
+    int child = base;
+    uint2 clk = make_uint2(0u, 0u);
+    if (sub < k) {
+      child = base + sub;
+      const int n = t.visit[child];
+      const double vs = t.value_sum[child];
+      const double pr = t.prior[child];
+      clk = t.link[child];
+      const double u = sq / (double)(n + 1);
+      double conf = pr * u;
+      conf = conf * cb;
+      double q = (n == 0) ? 0.0 : vs / (double)n;
+      if (negate) q = -q;
+      q = q * p.value_factor;
+      score = conf + q;
+      action = (int)meta_action(clk.y);
+    }
+    // max over (score, action): the larger action wins a tie (Explorer.py:100)
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1) {
+      const double os = __shfl_xor(score, w, LANES_PER_GAME);
+      const int oa = __shfl_xor(action, w, LANES_PER_GAME);
+      const int oc = __shfl_xor(child, w, LANES_PER_GAME);
+      const uint32_t ox = __shfl_xor(clk.x, w, LANES_PER_GAME);
+      const uint32_t oy = __shfl_xor(clk.y, w, LANES_PER_GAME);
+      if (os > score || (os == score && oa > action)) {
+        score = os; action = oa; child = oc; clk.x = ox; clk.y = oy;
+      }
+    }
+    d.sb = ttt_step(d.sb, action);
+    d.node = child;
+    d.lk = clk;
+    if (sub == d.path_len) my_node = child;
+    ++d.path_len;
+  }
+  return d;
+}
+
+// Root noise (Explorer.py:201-210): lane j mixes child j's prior.
+__device__ __forceinline__ void noise_row(const TreeParams& p, const Arena& t, int root, const double* noise_row9,
+                                          int sub) {
+  const uint2 lk = t.link[root];
+  const int k = (int)meta_children(lk.y);
+  if (sub < k) {
+    const int c = (int)lk.x + sub;
+    const double a = t.prior[c] * p.one_minus_frac;
+    const double b = noise_row9[sub] * p.frac;
+    t.prior[c] = a + b;
+  }
+}
+
+// ---- end of a move, one thread per game ----------------------------------------
+// numpy pairwise sum for n <= 9 values held in an array
+__device__ inline double np_sum(const double* v, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r = r + v[i];
+    return r;
+  }
+  double r = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  for (int i = 8; i < n; ++i) r = r + v[i];
+  return r;
+}
+// np.random.choice(p=...): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+__device__ inline int np_choice(const double* prob, int n, double u) {
+  double cdf[TTT_ACTIONS];
+  double run = 0.0;
+  for (int i = 0; i < n; ++i) {
+    run = (i == 0) ? prob[0] : run + prob[i];
+    cdf[i] = run;
+  }
+  const double last = cdf[n - 1];
+  int idx = 0;
+  while (idx < n && !(cdf[idx] / last > u)) ++idx;
+  return idx < n ? idx : n - 1;
+}
+
+struct MoveResult {
+  int chosen;        // action index, -1 if the search had not completed
+  int new_root;
+  uint32_t new_board;
+  int term;          // terminal code of the new position
+  int new_children;  // children of the new root
+};
+// Explorer.select_action (Explorer.py:70-97), the per-move records Gamer keeps
+// (Gamer.py:71-77,81-92), game.step (tic_tac_toe.py:161-167) and re-rooting
+// (Gamer.py:78-79).  `record` is the game's row in the hist_* arrays.
+__device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t, int record, int root,
+                                             uint32_t board, int move, const double* uni3) {
+  MoveResult r{-1, root, board, 0, 0};
+  const uint2 lk = t.link[root];
+  const int k = (int)meta_children(lk.y);
+  const int base = (int)lk.x;
+  const int gm = record * TTT_MAX_MOVES + move;
+  if (k == 0) {
+    atomicOr(p.error_flag, 4);      // search did not complete
+    return r;
+  }
+  int counts[TTT_ACTIONS], actions[TTT_ACTIONS];
+  for (int j = 0; j < k; ++j) {
+    const int c = base + j;
+    counts[j] = t.visit[c];
+    actions[j] = (int)meta_action(t.link[c].y);
+    p.hist_visits[gm * TTT_ACTIONS + actions[j]] = counts[j];
+    p.hist_prior[gm * TTT_ACTIONS + actions[j]] = t.prior[c];
+    p.hist_value_sum[gm * TTT_ACTIONS + actions[j]] = t.value_sum[c];
+  }
+  const int root_visits = t.visit[root];
+  p.hist_board[gm] = board;
+  p.hist_tree_size[gm] = root_visits;
+  p.hist_children[gm] = k;
+  p.hist_bias[gm] = root_visits < p.tab_len ? p.bias_tab[root_visits] : 0.0;
+  p.hist_root_value_sum[gm] = t.value_sum[root];
+
+  int mode = 0;       // 0 max, 1 softmax over visit counts, 2 uniform over legal
+  double u3 = 0.0;
+  if (p.training) {
+    const double u1 = uni3[0], u2 = uni3[1];
+    u3 = uni3[2];
+    if (move < p.softmax_moves) mode = 1;
+    else if (u1 < p.eps_softmax) mode = 1;
+    else if (u2 < p.eps_random) mode = 2;
+  }
+  int chosen;
+  if (mode == 0) {            // max_action: first maximum in child order
+    int best = 0;
+    for (int j = 1; j < k; ++j)
+      if (counts[j] > counts[best]) best = j;
+    chosen = actions[best];
+  } else if (mode == 1) {     // softmax_action (Explorer.py:187-199)
+    int mx = counts[0];
+    for (int j = 1; j < k; ++j) mx = counts[j] > mx ? counts[j] : mx;
+    double e[TTT_ACTIONS];
+    for (int j = 0; j < k; ++j) e[j] = exp((double)(counts[j] - mx));
+    const double s = np_sum(e, k);
+    for (int j = 0; j < k; ++j) e[j] = e[j] / s;
+    const double s2 = np_sum(e, k);
+    for (int j = 0; j < k; ++j) e[j] = e[j] / s2;
+    chosen = actions[np_choice(e, k, u3)];
+  } else {                    // uniform over legal actions (Explorer.py:86-89)
+    const uint32_t empty = ttt_empty(board);
+    double m[TTT_ACTIONS];
+    for (int a = 0; a < TTT_ACTIONS; ++a) m[a] = ((empty >> a) & 1u) ? 1.0 : 0.0;
+    const double n_valid = np_sum(m, TTT_ACTIONS);
+    for (int a = 0; a < TTT_ACTIONS; ++a) m[a] = m[a] / n_valid;
+    chosen = np_choice(m, TTT_ACTIONS, u3);
+  }
+  p.hist_action[gm] = chosen;
+  r.chosen = chosen;
+  r.new_board = ttt_step(board, chosen);
+  r.new_root = base;
+  for (int j = 0; j < k; ++j)
+    if (actions[j] == chosen) r.new_root = base + j;
+  r.term = ttt_terminal(r.new_board);
+  r.new_children = (int)meta_children(t.link[r.new_root].y);
+  return r;
+}
+
+__device__ inline void hist_clear(const TreeParams& p, int record) {
+  for (int m = 0; m < TTT_MAX_MOVES; ++m) {
+    const int gm = record * TTT_MAX_MOVES + m;
+    p.hist_board[gm] = 0u;
+    p.hist_action[gm] = -1;
+    p.hist_tree_size[gm] = 0;
+    p.hist_children[gm] = 0;
+    p.hist_bias[gm] = 0.0;
+    p.hist_root_value_sum[gm] = 0.0;
+    for (int a = 0; a < TTT_ACTIONS; ++a) {
+      p.hist_visits[gm * TTT_ACTIONS + a] = 0;
+      p.hist_prior[gm * TTT_ACTIONS + a] = 0.0;
+      p.hist_value_sum[gm * TTT_ACTIONS + a] = 0.0;
+    }
+  }
+}
+
+}  // namespace nz

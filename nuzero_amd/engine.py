@@ -127,6 +127,16 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             check(lib.nz_engine_play(self._h, int(base_seed), _stream()), self._h)
 
+    def play_lockstep(self, base_seed=0):
+        """Same results as play() by the lock-step route (one launch sequence per move)."""
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_play_lockstep(self._h, int(base_seed), _stream()), self._h)
+
+    def desync_count(self):
+        n = c_int64(0)
+        check(lib.nz_engine_desync_count(self._h, byref(n)), self._h)
+        return n.value
+
     def play_with_numpy_rng(self, seeds):
         """Same as play(), but the randomness is drawn here from numpy
         RandomState objects in the reference's call order -- the slow,

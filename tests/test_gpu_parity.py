@@ -63,15 +63,21 @@ def test_table_search_matches_reference(search_kat, net_kat, case_name):
     eng.close()
 
 
-def test_engine_random_streams_equal_numpy(search_kat, net_kat):
-    """nz_engine_play (host MT19937 streams inside the library) reproduces the
+@pytest.mark.parametrize("route", ["persistent", "lockstep"])
+def test_engine_random_streams_equal_numpy(search_kat, net_kat, route):
+    """nz_engine_play (persistent self-play kernel, randomness pre-drawn from the
+    library's host MT19937 streams) and nz_engine_play_lockstep reproduce the
     reference games too: seeds base..base+G-1."""
-    for case_name in ("legacy100_A", "explore50_B", "alpha_ge1_A"):
+    for case_name in ("legacy100_A", "legacy25_A", "legacy100_B", "explore50_B", "alpha_ge1_A", "sims2_A",
+                      "sims400_C"):
         case = search_kat[case_name]
         games = case["games"]
         eng = _engine(case["config"], len(games), training=True)
         eng.set_table(full_table(net_kat, case["table"]))
-        eng.play(base_seed=games[0]["seed"])
+        if route == "persistent":
+            eng.play(base_seed=games[0]["seed"])
+        else:
+            eng.play_lockstep(base_seed=games[0]["seed"])
         _compare_with_reference_games(eng.export(trace=True), games)
         c = eng.counters()
         assert c["simulations"] == sum(g["length"] for g in games) * case["config"]["Simulation"]["mcts_simulations"]
@@ -120,6 +126,46 @@ def test_network_batch_slot_invariance(net_kat):
     eng.close()
 
 
+def test_eval_mode_persistent(search_kat, net_kat):
+    """training=False (MctsAgent's use of run_mcts): no noise, max action."""
+    case = search_kat["eval40_B"]
+    eng = _engine(case["config"], 1, training=False)
+    eng.set_table(full_table(net_kat, case["table"]))
+    eng.play(base_seed=0)
+    _compare_with_reference_games(eng.export(trace=True), case["games"])
+    eng.close()
+
+
+def test_desynced_games_are_replayed(net_kat):
+    """With 3 simulations per move and always-random move selection the chosen
+    child is often unvisited, so the next root is unexpanded and the persistent
+    kernel's pre-drawn randomness does not fit: those games must come back
+    through the lock-step replay, and every game must equal the oracle's."""
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import ttt as ottt, search as osearch
+    cfg = legacy_ttt_search_config(3)
+    cfg["Exploration"]["epsilon_random_exploration"] = 1.0
+    table = full_table(net_kat, "B")
+    eng = _engine(cfg, 40)
+    eng.set_table(table)
+    eng.play(base_seed=77)
+    assert 0 < eng.desync_count() <= 40
+    r = eng.export(trace=True)
+    ev = osearch.table_evaluator(table)
+    for g in range(40):
+        game = ottt.TicTacToe()
+        trace = []
+        osearch.play_game(game, ev, cfg, np.random.RandomState(77 + g), trace=trace)
+        assert r["lengths"][g] == game.length and r["outcomes"][g] == game.terminal_value
+        for m, mv in enumerate(trace):
+            assert r["actions"][g, m] == mv["action"]
+            want = np.zeros(9, np.int64)
+            want[mv["child_actions"]] = mv["child_visits"]
+            assert np.array_equal(r["visits"][g, m], want)
+            assert r["child_prior"][g, m][mv["child_actions"]].tolist() == mv["child_priors"]
+    eng.close()
+
+
 def _gpu_table(eng):
     """Evaluate the engine's own network on every position code -> [19683,10]."""
     codes = np.arange(3 ** 9)
@@ -130,8 +176,9 @@ def _gpu_table(eng):
     return t
 
 
-@pytest.mark.parametrize("sims,n_games,net", [(100, 96, "A"), (25, 64, "B")])
-def test_fused_search_equals_oracle_on_same_evaluations(sims, n_games, net):
+@pytest.mark.parametrize("route", ["persistent", "lockstep"])
+@pytest.mark.parametrize("sims,n_games,net", [(100, 96, "A"), (25, 72, "B")])
+def test_fused_search_equals_oracle_on_same_evaluations(sims, n_games, net, route):
     """End to end with the network fused into the search.  The oracle is given
     the GPU network's own outputs as a table, so every tree decision must match
     exactly; the network's closeness to the reference is test_network_matches_reference."""
@@ -143,7 +190,10 @@ def test_fused_search_equals_oracle_on_same_evaluations(sims, n_games, net):
     eng = _engine(cfg, n_games)
     eng.set_weights(synthetic_recurrent_net_weights(seed, 2, 1, 64, 2, True, gain))
     table = _gpu_table(eng)
-    eng.play(base_seed=1000)
+    if route == "persistent":
+        eng.play(base_seed=1000)
+    else:
+        eng.play_lockstep(base_seed=1000)
     r = eng.export(trace=True)
     counters = eng.counters()
     ev = osearch.table_evaluator(table)
