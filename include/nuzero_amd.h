@@ -78,7 +78,8 @@ typedef struct nz_net_desc {
 
 /* Fixed per-engine sizes, for sizing the caller's export buffers. */
 typedef struct nz_dims {
-  int32_t n_games;
+  int32_t n_games;                      /* games per self-play round */
+  int32_t n_slots;                      /* games in flight at once */
   int32_t num_actions;                  /* A */
   int32_t max_moves;                    /* T */
   int32_t state_channels, rows, cols;   /* C, H, W */
@@ -94,6 +95,13 @@ const char* nz_last_error(const nz_engine* e);
  * per-game `game_class(*game_args)` / `Node(0)` set-up (Gamer.py:52,59). */
 nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game,
                            int32_t n_games, int32_t device);
+/* As nz_engine_create, with the concurrency separate from the round size: a
+ * round of n_games games is played on n_slots (<= n_games) concurrent trees; a
+ * slot whose game ends takes the next unplayed game, as the reference's
+ * ActorPool of num_actors Gamers does for num_games_per_step games
+ * (Training/AlphaZero.py:525-577).  nz_engine_create is n_slots == n_games. */
+nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game,
+                              int32_t n_slots, int32_t n_games, int32_t device);
 void nz_engine_destroy(nz_engine* e);
 nz_status nz_engine_dims(const nz_engine* e, nz_dims* out);
 
@@ -198,12 +206,28 @@ nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host);
 nz_status nz_net_forward(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev,
                          float* value_dev, float* probs_dev, void* stream);
 
+/* Diagnostic build of the network kernel: mean shader-clock ticks wave 0 of a
+ * workgroup spends [0] computing its jobs (K loops, input-plane step, epilogue),
+ * [1] waiting at the stage barriers; [2], [3] reserved.  Synchronises. */
+nz_status nz_net_forward_stamps(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev,
+                                float* value_dev, double* ticks4_host);
+
 /* Timing of the engine's own kernels, measured with HIP events on the stream
  * the kernels run on.  Enable, run, then read: total milliseconds and launch
  * count per kernel class (0 = tree advance, 1 = network, 2 = move/noise/export). */
 nz_status nz_engine_profile(nz_engine* e, int32_t enable);
 nz_status nz_engine_profile_read(nz_engine* e, double* ms_host /*[3]*/, int64_t* launches_host /*[3]*/,
                                  int64_t* net_positions_host);
+
+/* Diagnostic build of the persistent kernel: with `enable` the next
+ * nz_engine_play runs the stamped variant (shader-clock ticks per phase).  If
+ * out4_host is not NULL it first receives the last stamped run's figures:
+ * [0] mean tree/net cycles per workgroup, [1] share of ticks in the tree phase,
+ * [2] share in the network phase, [3] mean / max workgroup lifetime (how evenly
+ * the workgroups finish), [4] shader-clock ticks per network phase, [5] per tree
+ * phase, [6] ticks of the longest-lived workgroup, [7] workgroups.  Run times of
+ * the stamped build are not quoted. */
+nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out8_host);
 
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream

@@ -41,7 +41,7 @@ class NetDesc(Structure):
 
 
 class Dims(Structure):
-    _fields_ = [("n_games", c_int32), ("num_actions", c_int32), ("max_moves", c_int32),
+    _fields_ = [("n_games", c_int32), ("n_slots", c_int32), ("num_actions", c_int32), ("max_moves", c_int32),
                 ("state_channels", c_int32), ("rows", c_int32), ("cols", c_int32),
                 ("node_capacity", c_int32)]
 
@@ -51,6 +51,8 @@ SIGNATURES = {
     "nz_version": (c_char_p, []),
     "nz_last_error": (c_char_p, [c_void_p]),
     "nz_engine_create": (c_int32, [POINTER(c_void_p), POINTER(SearchCfg), POINTER(GameDesc), c_int32, c_int32]),
+    "nz_engine_create_ex": (c_int32, [POINTER(c_void_p), POINTER(SearchCfg), POINTER(GameDesc), c_int32, c_int32,
+                                      c_int32]),
     "nz_engine_destroy": (None, [c_void_p]),
     "nz_engine_dims": (c_int32, [c_void_p, POINTER(Dims)]),
     "nz_engine_set_weights": (c_int32, [c_void_p, POINTER(NetDesc), POINTER(c_void_p), c_int32, c_int32]),
@@ -69,8 +71,10 @@ SIGNATURES = {
     "nz_engine_counters_ex": (c_int32, [c_void_p, POINTER(c_int64), c_void_p]),
     "nz_engine_net_flops": (c_int32, [c_void_p, POINTER(c_double)]),
     "nz_net_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_net_forward_stamps": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, POINTER(c_double)]),
     "nz_engine_profile": (c_int32, [c_void_p, c_int32]),
     "nz_engine_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_int64)]),
+    "nz_engine_phase_stamps": (c_int32, [c_void_p, c_int32, POINTER(c_double)]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

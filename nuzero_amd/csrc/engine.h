@@ -32,7 +32,9 @@ struct TreeParams {
   double* prior;
   uint2* link;            // x = index of first child, y = packed meta
   int32_t cap;
-  int32_t n_games;
+  int32_t n_games;        // games per self-play round (records, random tables)
+  int32_t n_slots;        // games in flight at once (tree arenas); lock-step needs n_slots == n_games
+  int32_t* next_game;     // work queue head of the persistent kernel
   // per-game state
   uint32_t* board;        // live game: player-one stones | player-two stones << 16
   int32_t* length;
@@ -90,30 +92,38 @@ void launch_export_states(const TreeParams& p, float* states, hipStream_t s);
 void launch_export_visits(const TreeParams& p, int32_t* visits, int32_t* actions, int32_t* tree_size,
                           int32_t* n_children, double* bias, hipStream_t s);
 
+int selfplay_blocks(int n_games);
+// stamps != nullptr selects the diagnostic build ([blocks][4] phase ticks, see selfplay.hip)
 void launch_selfplay(const TreeParams& p, const struct NetProgram* prog_dev, int n_layers, const float* weights,
-                     const double* noise, const double* uniforms, hipStream_t s);
+                     const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s);
 
 // ---- network ----------------------------------------------------------------
-struct NetLayer {
-  int32_t cin_main;    // channels read from the activation buffer (multiple of 16 after padding)
-  int32_t kgroups;     // cin_main / 16
-  int32_t extra;       // 1: also read the (<=4) input planes as one extra K step
-  int32_t cout;        // real output channels
-  int32_t ntiles;      // ceil(cout / 16)
-  int32_t src, dst;    // activation buffer ids (0/1); dst 2 = policy out, 3 = value out
-  int32_t res;         // residual buffer id or -1
-  int32_t act;         // 0 none, 1 relu, 2 tanh
-  int32_t w_off;       // float offset of the packed main weights
-  int32_t wx_off;      // float offset of the packed extra-plane weights
+// The network is compiled on the host into one job list per wave (net_dev.hpp).
+// A job is one (conv layer, 16-channel output tile, output-cell group) unit; the
+// jobs of a stage are independent, a workgroup barrier separates stages.
+struct NetJob {
+  int32_t w_off;       // float offset of this (layer, n-tile)'s packed main weights [kgroup][tap][lane][4]
+  int32_t wx_off;      // float offset of its packed input-plane weights [tap][lane]
+  int16_t kgroups;     // 16-channel K groups read from the source activation buffer
+  int16_t nt;          // output tile: channels 16 nt .. 16 nt + 15
+  int8_t extra;        // 1: also read the (<= 4) input planes as one extra K step
+  int8_t og;           // output-cell group (net_dev.hpp OG_MASK); OG_NONE = no work, barrier only
+  int8_t src, dst;     // activation buffers 0..2; dst 3 = policy logits out, 4 = value out
+  int8_t res;          // residual buffer or -1
+  int8_t act;          // 0 none, 1 relu, 2 tanh
+  int8_t stage_end;    // 1: workgroup barrier after this job
+  int8_t pad;
 };
-constexpr int NET_MAX_LAYERS = 128;
+constexpr int NET_WAVES_HOST = 4;
+constexpr int NET_MAX_JOBS = 192;
+constexpr int OG_NONE = 7;
 struct NetProgram {
-  int32_t n_layers;
-  NetLayer layers[NET_MAX_LAYERS];
+  int32_t n_jobs[NET_WAVES_HOST];
+  NetJob jobs[NET_WAVES_HOST][NET_MAX_JOBS];
 };
 
 void launch_net(const NetProgram* prog_dev, int n_layers, const float* packed_weights,
                 const uint32_t* boards, const float* states, const int32_t* count_dev, int max_positions,
-                float* logits, float* value, float* probs, hipStream_t s);
+                float* logits, float* value, float* probs, unsigned long long* stamps, hipStream_t s);
 
 }  // namespace nz

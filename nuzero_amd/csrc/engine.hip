@@ -27,7 +27,8 @@ struct nz_engine {
   nz_search_cfg cfg;
   nz_game_desc game;
   int device = 0;
-  int n_games = 0;
+  int n_games = 0;   // games per round
+  int n_slots = 0;   // games in flight
   int cap = 0;
   int tab_len = 0;
   TreeParams tp;
@@ -61,6 +62,8 @@ struct nz_engine {
   bool borrowed_net = false;          // fallback engine: network buffers belong to the parent
   nz_engine* fallback = nullptr;
   int64_t desync_total = 0;
+  unsigned long long* d_stamps = nullptr;   // [blocks][4], diagnostic build only
+  bool stamps = false;
   // profiling
   bool profile = false;
   std::vector<ProfileSpan> spans;
@@ -125,36 +128,92 @@ int head_channel(int width, int out, int n_layers, int idx) {   // blocks.py:56-
   return c;
 }
 
-// Repack one conv's [Cout][Cin][3][3] weights into the per-lane order the MFMA
-// kernel reads (net.hip): main[tap][kgroup][ntile][lane][4], extra[tap][ntile][lane].
-void pack_conv(const float* w, int cout, int cin, int cin_main, std::vector<float>& out, NetLayer& ly) {
-  const int ntiles = (cout + 15) / 16;
-  const int kgroups = (cin_main + 15) / 16;
+// One conv tensor repacked for the MFMA kernel (net_dev.hpp): per 16-channel output
+// tile nt a contiguous weight stream main[nt][kgroup][tap][lane][4] and, for the two
+// convs that also read the raw input planes, extra[nt][tap][lane].
+struct PackedConv {
+  int cout, cin, cin_main, kgroups, ntiles, extra;
+  int32_t w_off, wx_off;
+};
+PackedConv pack_conv(const float* w, int cout, int cin, int cin_main, std::vector<float>& out) {
+  PackedConv pc{};
+  pc.cout = cout; pc.cin = cin; pc.cin_main = cin_main;
+  pc.ntiles = (cout + 15) / 16;
+  pc.kgroups = (cin_main + 15) / 16;
+  pc.extra = cin > cin_main ? 1 : 0;
   while (out.size() % 4) out.push_back(0.f);
-  ly.w_off = (int32_t)out.size();
-  ly.cin_main = kgroups * 16;
-  ly.kgroups = kgroups;
-  ly.cout = cout;
-  ly.ntiles = ntiles;
-  for (int t = 0; t < 9; ++t)
-    for (int kg = 0; kg < kgroups; ++kg)
-      for (int nt = 0; nt < ntiles; ++nt)
+  pc.w_off = (int32_t)out.size();
+  for (int nt = 0; nt < pc.ntiles; ++nt)
+    for (int kg = 0; kg < pc.kgroups; ++kg)
+      for (int t = 0; t < 9; ++t)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
             const int co = nt * 16 + (lane & 15);
             const int ci = kg * 16 + (lane >> 4) * 4 + j;
             out.push_back(co < cout && ci < cin_main ? w[((size_t)co * cin + ci) * 9 + t] : 0.f);
           }
-  ly.extra = cin > cin_main ? 1 : 0;
-  ly.wx_off = (int32_t)out.size();
-  if (ly.extra)
-    for (int t = 0; t < 9; ++t)
-      for (int nt = 0; nt < ntiles; ++nt)
+  pc.wx_off = (int32_t)out.size();
+  if (pc.extra)
+    for (int nt = 0; nt < pc.ntiles; ++nt)
+      for (int t = 0; t < 9; ++t)
         for (int lane = 0; lane < 64; ++lane) {
           const int co = nt * 16 + (lane & 15);
           const int ci = cin_main + (lane >> 4);
           out.push_back(co < cout && ci < cin ? w[((size_t)co * cin + ci) * 9 + t] : 0.f);
         }
+  return pc;
+}
+
+// A stage of the network = convs that may run side by side.  Its units (conv, output tile,
+// output-cell group) are dealt to the four waves longest-first; every wave's last job of the
+// stage carries the barrier.
+struct StageConv {
+  int tensor, src, dst, res, act;
+  bool split;   // cut each output tile into the four output-cell groups as well
+};
+bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::vector<StageConv>& stage) {
+  static const int og_taps[5] = {49, 13, 12, 12, 12};
+  struct Unit { NetJob job; int cost; };
+  std::vector<Unit> units;
+  for (const StageConv& sc : stage) {
+    const PackedConv& pc = convs[sc.tensor];
+    for (int nt = 0; nt < pc.ntiles; ++nt) {
+      const int og_first = sc.split ? 1 : 0, og_last = sc.split ? 4 : 0;
+      for (int og = og_first; og <= og_last; ++og) {
+        NetJob j{};
+        j.w_off = pc.w_off + nt * pc.kgroups * 9 * 256;
+        j.wx_off = pc.wx_off + nt * 9 * 64;
+        j.kgroups = (int16_t)pc.kgroups;
+        j.nt = (int16_t)nt;
+        j.extra = (int8_t)pc.extra;
+        j.og = (int8_t)og;
+        j.src = (int8_t)sc.src; j.dst = (int8_t)sc.dst; j.res = (int8_t)sc.res; j.act = (int8_t)sc.act;
+        units.push_back({j, og_taps[og] * (4 * pc.kgroups + pc.extra)});
+      }
+    }
+  }
+  std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
+  int load[NET_WAVES_HOST] = {0, 0, 0, 0};
+  int first[NET_WAVES_HOST];
+  for (int w = 0; w < NET_WAVES_HOST; ++w) first[w] = pg.n_jobs[w];
+  for (const Unit& u : units) {
+    int w = 0;
+    for (int i = 1; i < NET_WAVES_HOST; ++i)
+      if (load[i] < load[w]) w = i;
+    if (pg.n_jobs[w] >= NET_MAX_JOBS) return false;
+    pg.jobs[w][pg.n_jobs[w]++] = u.job;
+    load[w] += u.cost;
+  }
+  for (int w = 0; w < NET_WAVES_HOST; ++w) {
+    if (pg.n_jobs[w] == first[w]) {            // nothing to do in this stage: barrier only
+      if (pg.n_jobs[w] >= NET_MAX_JOBS) return false;
+      NetJob j{};
+      j.og = OG_NONE;
+      pg.jobs[w][pg.n_jobs[w]++] = j;
+    }
+    pg.jobs[w][pg.n_jobs[w] - 1].stage_end = 1;
+  }
+  return true;
 }
 
 hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
@@ -179,7 +238,14 @@ const char* nz_last_error(const nz_engine* e) { return e ? e->error.c_str() : g_
 
 nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game, int32_t n_games,
                            int32_t device) {
+  return nz_engine_create_ex(out, cfg, game, n_games, n_games, device);
+}
+
+nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const nz_game_desc* game, int32_t n_slots,
+                              int32_t n_games, int32_t device) {
   if (!out || !cfg || !game) return fail(nullptr, NZ_ERR_ARG, "null argument");
+  if (n_slots <= 0) return fail(nullptr, NZ_ERR_ARG, "n_slots must be positive");
+  if (n_slots > n_games) n_slots = n_games > 0 ? n_games : n_slots;
   *out = nullptr;
   if (game->game != NZ_GAME_TIC_TAC_TOE) return fail(nullptr, NZ_ERR_ARG, "unsupported game %d", game->game);
   if (n_games <= 0) return fail(nullptr, NZ_ERR_ARG, "n_games must be positive");
@@ -198,6 +264,7 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
   e->game = *game;
   e->device = device;
   e->n_games = n_games;
+  e->n_slots = n_slots;
   // every expansion at move m adds at most 9 - m children: 1 + sims * (9 + 8 + ... + 1)
   e->cap = 1 + cfg->mcts_simulations * 45;
   e->tab_len = cfg->mcts_simulations * TTT_MAX_MOVES + 2;
@@ -211,7 +278,7 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
 
   TreeParams& p = e->tp;
   memset(&p, 0, sizeof(p));
-  const size_t G = n_games, N = G * (size_t)e->cap, GT = G * TTT_MAX_MOVES, GTA = GT * TTT_ACTIONS;
+  const size_t G = n_games, N = (size_t)n_slots * (size_t)e->cap, GT = G * TTT_MAX_MOVES, GTA = GT * TTT_ACTIONS;
 #define A(ptr, n)                                        \
   if ((st = dev_alloc(e, &(ptr), (n))) != NZ_OK) return bail(st)
   A(p.visit, N); A(p.value_sum, N); A(p.prior, N); A(p.link, N);
@@ -227,12 +294,15 @@ nz_status nz_engine_create(nz_engine** out, const nz_search_cfg* cfg, const nz_g
   A(bias_tab, e->tab_len); A(sqrt_tab, e->tab_len);
   A(e->d_noise, G * TTT_ACTIONS); A(e->d_uniforms, G * 3);
   A(e->d_game_noise, GTA); A(e->d_game_uniforms, GT * 3);
+  A(e->d_stamps, (size_t)selfplay_blocks(n_slots) * 4);
+  A(p.next_game, 1);
   A(e->prog_dev, 1);
 #undef A
   p.leaf_logits = e->leaf_logits;
   p.leaf_value = e->leaf_value;
   p.cap = e->cap;
   p.n_games = n_games;
+  p.n_slots = n_slots;
   p.table = nullptr;
   p.tab_len = e->tab_len;
   p.sims = cfg->mcts_simulations;
@@ -303,6 +373,7 @@ void nz_engine_destroy(nz_engine* e) {
 nz_status nz_engine_dims(const nz_engine* e, nz_dims* out) {
   if (!e || !out) return NZ_ERR_ARG;
   out->n_games = e->n_games;
+  out->n_slots = e->n_slots;
   out->num_actions = TTT_ACTIONS;
   out->max_moves = TTT_MAX_MOVES;
   out->state_channels = 2;
@@ -323,7 +394,7 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   const int expect = 1 + (net->recall ? 1 : 0) + 2 * net->num_blocks + 2 + 4;
   if (n_tensors != expect) return fail(e, NZ_ERR_ARG, "expected %d weight tensors, got %d", expect, n_tensors);
   const int per_iter = (net->recall ? 1 : 0) + 2 * net->num_blocks;
-  if (1 + recurrent_iterations * per_iter + 6 > NET_MAX_LAYERS)
+  if (1 + recurrent_iterations * per_iter + 24 > NET_MAX_JOBS)
     return fail(e, NZ_ERR_ARG, "too many layers for one fused launch (%d iterations)", recurrent_iterations);
   NZ_HIP(e, hipSetDevice(e->device));
 
@@ -345,42 +416,41 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   }
 
   std::vector<float> packed;
-  std::vector<NetLayer> tensors(n_tensors);
+  std::vector<PackedConv> convs(n_tensors);
+  double flops = 0.0;   // in-bounds taps only: 2 * Cout * Cin * 49 per conv application
   for (int i = 0; i < n_tensors; ++i) {
     const bool with_planes = (i == 0) || (net->recall && i == 1);
     const int cin_main = with_planes ? shapes[i].cin - IN : shapes[i].cin;
-    pack_conv(host[i].data(), shapes[i].cout, shapes[i].cin, cin_main, packed, tensors[i]);
+    convs[i] = pack_conv(host[i].data(), shapes[i].cout, shapes[i].cin, cin_main, packed);
   }
 
-  // layer program: buffer 0/1 ping-pong, `cur` holds the running thought
+  // stages; activation buffers 0/1 ping-pong, `cur` holds the running thought, 2 is the
+  // value head's side buffer; dst 3 = policy logits, 4 = value
   NetProgram& pg = e->prog_host;
   memset(&pg, 0, sizeof(pg));
-  int n = 0, cur = 0;
-  double flops = 0.0;   // in-bounds taps only: 2 * Cout * Cin * 49 per conv
-  auto emit = [&](int tensor, int src, int dst, int res, int act) {
-    NetLayer ly = tensors[tensor];
-    ly.src = src; ly.dst = dst; ly.res = res; ly.act = act;
-    pg.layers[n++] = ly;
-    flops += 2.0 * shapes[tensor].cout * shapes[tensor].cin * 49.0;
+  bool ok = true;
+  int cur = 0;
+  auto stage = [&](std::vector<StageConv> convs_in_stage) {
+    for (const StageConv& sc : convs_in_stage) flops += 2.0 * shapes[sc.tensor].cout * shapes[sc.tensor].cin * 49.0;
+    ok = ok && add_stage(pg, convs, convs_in_stage);
   };
-  emit(0, 0, cur, -1, 1);                                  // projection + ReLU
+  stage({{0, 0, cur, -1, 1, false}});                                   // projection + ReLU
   const int first_block = net->recall ? 2 : 1;
   for (int it = 0; it < recurrent_iterations; ++it) {
-    if (net->recall) { emit(1, cur, cur ^ 1, -1, 0); cur ^= 1; }      // cat([thought, x]) conv, no activation
-    for (int b = 0; b < net->num_blocks; ++b) {                        // relu(conv2(relu(conv1(t))) + t)
-      emit(first_block + 2 * b, cur, cur ^ 1, -1, 1);
-      emit(first_block + 2 * b + 1, cur ^ 1, cur, cur, 1);
+    if (net->recall) { stage({{1, cur, cur ^ 1, -1, 0, false}}); cur ^= 1; }   // cat([thought, x]) conv, no activation
+    for (int b = 0; b < net->num_blocks; ++b) {                                    // relu(conv2(relu(conv1(t))) + t)
+      stage({{first_block + 2 * b, cur, cur ^ 1, -1, 1, false}});
+      stage({{first_block + 2 * b + 1, cur ^ 1, cur, cur, 1, false}});
     }
   }
   const int ph = first_block + 2 * net->num_blocks, vh = ph + 2;
   const int vact = net->value_activation == NZ_ACT_RELU ? 1 : 2;
-  emit(ph, cur, cur ^ 1, -1, 1);
-  emit(ph + 1, cur ^ 1, 2, -1, 0);
-  emit(vh, cur, cur ^ 1, -1, vact);
-  emit(vh + 1, cur ^ 1, cur, -1, vact);
-  emit(vh + 2, cur, cur ^ 1, -1, vact);
-  emit(vh + 3, cur ^ 1, 3, -1, 0);
-  pg.n_layers = n;
+  const int side = cur ^ 1;
+  stage({{ph, cur, side, -1, 1, true}, {vh, cur, 2, -1, vact, true}});      // both heads read the thought
+  stage({{ph + 1, side, 3, -1, 0, true}, {vh + 1, 2, cur, -1, vact, true}});
+  stage({{vh + 2, cur, side, -1, vact, true}});
+  stage({{vh + 3, side, 4, -1, 0, false}});                                 // mean over cells needs all nine
+  if (!ok) return fail(e, NZ_ERR_ARG, "network too deep for one fused launch (%d iterations)", recurrent_iterations);
   e->algorithmic_flops_per_position = flops;
 
   if (e->weights_dev) { (void)hipFree(e->weights_dev); e->weights_dev = nullptr; }
@@ -431,6 +501,8 @@ nz_status nz_engine_alive(nz_engine* e, int32_t* alive_dev, void* stream) {
 
 nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev, void* stream) {
   if (!e) return NZ_ERR_ARG;
+  if (e->n_slots != e->n_games)
+    return fail(e, NZ_ERR_STATE, "the lock-step route needs n_slots == n_games (every game of the round in flight)");
   if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
   if (e->cfg.training && (!noise_dev || !uniforms_dev))
     return fail(e, NZ_ERR_ARG, "training search needs noise and uniforms");
@@ -455,8 +527,8 @@ nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* un
       if (it == sims) break;
       {
         Span sp(e, s, 1);
-        launch_net(e->prog_dev, e->prog_host.n_layers, e->weights_dev, p.leaf_boards, nullptr,
-                   p.leaf_count + (it & 1), e->n_games, e->leaf_logits, e->leaf_value, nullptr, s);
+        launch_net(e->prog_dev, 0, e->weights_dev, p.leaf_boards, nullptr,
+                   p.leaf_count + (it & 1), e->n_games, e->leaf_logits, e->leaf_value, nullptr, nullptr, s);
       }
     }
   }
@@ -509,6 +581,8 @@ static void ensure_rngs(nz_engine* e) {
 // Lock-step play: one host round trip per move to learn each root's child count
 // before drawing.  `seeds[g]` seeds game g's stream.
 static nz_status play_lockstep(nz_engine* e, const uint32_t* seeds, void* stream) {
+  if (e->n_slots != e->n_games)
+    return fail(e, NZ_ERR_STATE, "the lock-step route needs n_slots == n_games (every game of the round in flight)");
   hipStream_t s = as_stream(stream);
   const int G = e->n_games;
   const nz_search_cfg& c = e->cfg;
@@ -630,8 +704,9 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
   }
   {
     Span sp(e, s, 0);
-    launch_selfplay(e->tp, e->prog_dev, e->prog_host.n_layers, e->weights_dev,
-                    c.training ? e->d_game_noise : nullptr, c.training ? e->d_game_uniforms : nullptr, s);
+    launch_selfplay(e->tp, e->prog_dev, 0, e->weights_dev,
+                    c.training ? e->d_game_noise : nullptr, c.training ? e->d_game_uniforms : nullptr,
+                    e->stamps ? e->d_stamps : nullptr, s);
   }
   NZ_HIP(e, hipGetLastError());
   st = check_device_flag(e, s);
@@ -648,6 +723,33 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
       if (st != NZ_OK) return st;
     }
   }
+  return NZ_OK;
+}
+
+nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out4_host) {
+  if (!e) return NZ_ERR_ARG;
+  if (out4_host) {
+    const int blocks = selfplay_blocks(e->n_slots);
+    std::vector<unsigned long long> h((size_t)blocks * 4);
+    NZ_HIP(e, hipSetDevice(e->device));
+    NZ_HIP(e, hipDeviceSynchronize());
+    NZ_HIP(e, hipMemcpy(h.data(), e->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double sum[4] = {0, 0, 0, 0};
+    double max_total = 0;
+    for (int b = 0; b < blocks; ++b) {
+      for (int i = 0; i < 4; ++i) sum[i] += (double)h[b * 4 + i];
+      max_total = std::max(max_total, (double)h[b * 4 + 3]);
+    }
+    out4_host[0] = sum[0] / blocks;              // mean tree/net cycles per workgroup
+    out4_host[1] = sum[1] / std::max(sum[3], 1.0);   // share of ticks in the tree phase
+    out4_host[2] = sum[2] / std::max(sum[3], 1.0);   // share of ticks in the net phase
+    out4_host[3] = sum[3] / blocks / std::max(max_total, 1.0);   // mean / max workgroup lifetime
+    out4_host[4] = sum[2] / std::max(sum[0], 1.0);   // shader-clock ticks per network phase
+    out4_host[5] = sum[1] / std::max(sum[0], 1.0);   // shader-clock ticks per tree phase
+    out4_host[6] = max_total;                        // ticks of the longest-lived workgroup
+    out4_host[7] = (double)blocks;
+  }
+  e->stamps = enable != 0;
   return NZ_OK;
 }
 
@@ -730,9 +832,31 @@ nz_status nz_net_forward(nz_engine* e, const float* states_dev, int32_t batch, f
   if (batch <= 0) return NZ_OK;
   NZ_HIP(e, hipSetDevice(e->device));
   Span sp(e, as_stream(stream), 1);
-  launch_net(e->prog_dev, e->prog_host.n_layers, e->weights_dev, nullptr, states_dev, nullptr, batch, logits_dev,
-             value_dev, probs_dev, as_stream(stream));
+  launch_net(e->prog_dev, 0, e->weights_dev, nullptr, states_dev, nullptr, batch, logits_dev,
+             value_dev, probs_dev, nullptr, as_stream(stream));
   NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_net_forward_stamps(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev,
+                                float* value_dev, double* ticks4_host) {
+  if (!e || !states_dev || !logits_dev || !value_dev || !ticks4_host) return NZ_ERR_ARG;
+  if (!e->have_net) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  NZ_HIP(e, hipSetDevice(e->device));
+  const int blocks = (batch + 15) / 16;
+  unsigned long long* d = nullptr;
+  NZ_HIP(e, hipMalloc((void**)&d, (size_t)blocks * 4 * sizeof(unsigned long long)));
+  launch_net(e->prog_dev, 0, e->weights_dev, nullptr, states_dev, nullptr, batch, logits_dev, value_dev, nullptr, d,
+             nullptr);
+  std::vector<unsigned long long> h((size_t)blocks * 4);
+  hipError_t err = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(e, NZ_ERR_HIP, "stamp read-back failed: %s", hipGetErrorString(err));
+  for (int i = 0; i < 4; ++i) {
+    double sum = 0;
+    for (int b = 0; b < blocks; ++b) sum += (double)h[(size_t)b * 4 + i];
+    ticks4_host[i] = sum / blocks;
+  }
   return NZ_OK;
 }
 

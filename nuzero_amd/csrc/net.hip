@@ -6,15 +6,17 @@
 namespace nz {
 namespace {
 
+template <bool STAMPS>
 __global__ __launch_bounds__(NET_THREADS) void net_kernel(const NetProgram* __restrict__ prog, int n_layers,
                                                           const float* __restrict__ W,
                                                           const uint32_t* __restrict__ boards,
                                                           const float* __restrict__ states, int in_channels,
                                                           const int32_t* __restrict__ count_ptr, int max_positions,
                                                           int policy_channels, float* __restrict__ logits,
-                                                          float* __restrict__ value) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * ACT_FLOATS + INP_FLOATS];
-  float* const inp = lds + 2 * ACT_FLOATS;
+                                                          float* __restrict__ value,
+                                                          unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) float lds[NET_LDS_FLOATS];
+  float* const inp = lds + NET_BUFFERS * ACT_FLOATS;
 
   int count = max_positions;
   if (count_ptr != nullptr) {
@@ -36,8 +38,9 @@ __global__ __launch_bounds__(NET_THREADS) void net_kernel(const NetProgram* __re
     inp[idx] = v;
   }
   __syncthreads();
-  net_tile(prog, n_layers, W, lds, inp, policy_channels, count - tile0,
-           logits + (size_t)tile0 * policy_channels * CELLS, value + tile0);
+  net_tile<STAMPS>(prog, W, lds, inp, policy_channels, count - tile0,
+                   logits + (size_t)tile0 * policy_channels * CELLS, value + tile0,
+                   STAMPS ? stamps + blockIdx.x * 4 : nullptr);
 }
 
 // scipy softmax over each position's logits (Explorer.py:159), numpy sum order for n = 9
@@ -64,11 +67,15 @@ __global__ void softmax_kernel(const float* __restrict__ logits, float* __restri
 
 void launch_net(const NetProgram* prog_dev, int n_layers, const float* packed_weights, const uint32_t* boards,
                 const float* states, const int32_t* count_dev, int max_positions, float* logits, float* value,
-                float* probs, hipStream_t s) {
+                float* probs, unsigned long long* stamps, hipStream_t s) {
   const int blocks = (max_positions + POS - 1) / POS;
   if (blocks <= 0) return;
-  hipLaunchKernelGGL(net_kernel, dim3(blocks), dim3(NET_THREADS), 0, s, prog_dev, n_layers, packed_weights, boards,
-                     states, 2, count_dev, max_positions, 1, logits, value);
+  if (stamps != nullptr)
+    hipLaunchKernelGGL(net_kernel<true>, dim3(blocks), dim3(NET_THREADS), 0, s, prog_dev, n_layers, packed_weights,
+                       boards, states, 2, count_dev, max_positions, 1, logits, value, stamps);
+  else
+    hipLaunchKernelGGL(net_kernel<false>, dim3(blocks), dim3(NET_THREADS), 0, s, prog_dev, n_layers, packed_weights,
+                       boards, states, 2, count_dev, max_positions, 1, logits, value, stamps);
   if (probs != nullptr)
     hipLaunchKernelGGL(softmax_kernel, dim3((max_positions + 255) / 256), dim3(256), 0, s, logits, probs,
                        max_positions, 9);

@@ -23,9 +23,15 @@
 // each position's row is independent of the others, so a position's outputs do
 // not depend on which batch slot it occupies.
 //
-// Per 16-channel K group a wave loads 9 activation vectors (one ds_read_b128
-// per input cell) and 9 weight vectors (one global_load_dwordx4 per tap) and
-// issues 196 MFMAs from them.
+// Work split.  The host compiles the network into one job list per wave
+// (engine.hip build_program): a job is one (layer, 16-channel output tile,
+// output-cell group).  64-channel layers give each of the 4 waves one full
+// tile; the narrow head layers are cut by output-cell group as well so that all
+// four matrix pipes stay busy, and the policy and value heads run side by side.
+// Per 16-channel K group a wave reads at most 9 activation vectors (one
+// ds_read_b128 per input cell) and 9 weight vectors (one global_load_dwordx4 per
+// tap) and issues up to 196 MFMAs from them; the weights of the NEXT K group --
+// also across jobs and barriers -- are already in flight while it does so.
 //
 // LDS layout: act[buf][cell][pos][64 ch], the 16-byte slot index XOR-ed with
 // the position so that ds_read_b128 (A operands) and ds_write_b32 (epilogue) are
@@ -42,8 +48,17 @@ constexpr int CELLS = 9;
 constexpr int ROW = 64;            // channels per (cell, pos) row
 constexpr int NET_WAVES = 4;
 constexpr int NET_THREADS = NET_WAVES * 64;
+constexpr int NET_BUFFERS = 3;
 constexpr int ACT_FLOATS = CELLS * POS * ROW;
 constexpr int INP_FLOATS = CELLS * POS * 4;
+constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
+constexpr int W_KG_FLOATS = 9 * 64 * 4;   // one K group of one n-tile: [tap][lane][4]
+static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
+
+// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} (taps: 49 | 13, 12, 12, 12)
+__host__ __device__ constexpr int og_mask(int og) {
+  return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 : 0;
+}
 
 __device__ __forceinline__ int act_addr(int cell, int pos, int ch) {
   return ((cell * POS + pos) << 6) + ((((ch >> 2) ^ pos) & 15) << 2) + (ch & 3);
@@ -56,139 +71,277 @@ struct TapMap {   // output cell reached from input cell I through tap TAP
   static constexpr bool valid = oy >= 0 && oy < 3 && ox >= 0 && ox < 3;
   static constexpr int o = valid ? oy * 3 + ox : 0;
 };
+template <int OMASK, int I, int TAP>
+constexpr bool pair_used() { return TapMap<I, TAP>::valid && ((OMASK >> TapMap<I, TAP>::o) & 1); }
+template <int OMASK, int I>
+constexpr bool input_used() {
+  return pair_used<OMASK, I, 0>() || pair_used<OMASK, I, 1>() || pair_used<OMASK, I, 2>() ||
+         pair_used<OMASK, I, 3>() || pair_used<OMASK, I, 4>() || pair_used<OMASK, I, 5>() ||
+         pair_used<OMASK, I, 6>() || pair_used<OMASK, I, 7>() || pair_used<OMASK, I, 8>();
+}
 
-template <int J, int TAP, int I>
-__device__ __forceinline__ void mfma_pair(f32x4 (&acc)[CELLS], const f32x4 (&av)[CELLS], const f32x4 (&bw)[9]) {
-  if constexpr (TapMap<I, TAP>::valid) {
+struct Frag {          // operands of one 16-channel K group
+  f32x4 a[CELLS];      // activations per input cell: 4 consecutive channels of this lane's K slice
+  f32x4 b[9];          // weights per tap
+};
+
+template <int OMASK, int I, int TAP>
+__device__ __forceinline__ void mfma_pair(f32x4 (&acc)[CELLS], const Frag& f) {
+  if constexpr (pair_used<OMASK, I, TAP>()) {
     constexpr int o = TapMap<I, TAP>::o;
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[I][J], bw[TAP][J], acc[o], 0, 0, 0);
+    // the four K sub-steps of one (input cell, tap) pair back to back: a single accumulator
+    // chain issues at the full rate (scripts/microbench/mfma_rate.hip)
+    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][0], f.b[TAP][0], acc[o], 0, 0, 0);
+    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][1], f.b[TAP][1], acc[o], 0, 0, 0);
+    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][2], f.b[TAP][2], acc[o], 0, 0, 0);
+    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][3], f.b[TAP][3], acc[o], 0, 0, 0);
   }
 }
-template <int J, int TAP>
-__device__ __forceinline__ void mfma_tap(f32x4 (&acc)[CELLS], const f32x4 (&av)[CELLS], const f32x4 (&bw)[9]) {
-  mfma_pair<J, TAP, 0>(acc, av, bw); mfma_pair<J, TAP, 1>(acc, av, bw); mfma_pair<J, TAP, 2>(acc, av, bw);
-  mfma_pair<J, TAP, 3>(acc, av, bw); mfma_pair<J, TAP, 4>(acc, av, bw); mfma_pair<J, TAP, 5>(acc, av, bw);
-  mfma_pair<J, TAP, 6>(acc, av, bw); mfma_pair<J, TAP, 7>(acc, av, bw); mfma_pair<J, TAP, 8>(acc, av, bw);
+// input-cell major: the MFMAs of cell I only need the I-th LDS read to have landed
+template <int OMASK, int I>
+__device__ __forceinline__ void mfma_cell(f32x4 (&acc)[CELLS], const Frag& f) {
+  mfma_pair<OMASK, I, 0>(acc, f); mfma_pair<OMASK, I, 1>(acc, f); mfma_pair<OMASK, I, 2>(acc, f);
+  mfma_pair<OMASK, I, 3>(acc, f); mfma_pair<OMASK, I, 4>(acc, f); mfma_pair<OMASK, I, 5>(acc, f);
+  mfma_pair<OMASK, I, 6>(acc, f); mfma_pair<OMASK, I, 7>(acc, f); mfma_pair<OMASK, I, 8>(acc, f);
 }
-template <int J>
-__device__ __forceinline__ void mfma_step(f32x4 (&acc)[CELLS], const f32x4 (&av)[CELLS], const f32x4 (&bw)[9]) {
-  // tap-major: consecutive MFMAs accumulate into different output cells
-  mfma_tap<J, 0>(acc, av, bw); mfma_tap<J, 1>(acc, av, bw); mfma_tap<J, 2>(acc, av, bw);
-  mfma_tap<J, 3>(acc, av, bw); mfma_tap<J, 4>(acc, av, bw); mfma_tap<J, 5>(acc, av, bw);
-  mfma_tap<J, 6>(acc, av, bw); mfma_tap<J, 7>(acc, av, bw); mfma_tap<J, 8>(acc, av, bw);
+template <int OMASK>
+__device__ __forceinline__ void mfma_group(f32x4 (&acc)[CELLS], const Frag& f) {
+  mfma_cell<OMASK, 0>(acc, f); mfma_cell<OMASK, 1>(acc, f); mfma_cell<OMASK, 2>(acc, f);
+  mfma_cell<OMASK, 3>(acc, f); mfma_cell<OMASK, 4>(acc, f); mfma_cell<OMASK, 5>(acc, f);
+  mfma_cell<OMASK, 6>(acc, f); mfma_cell<OMASK, 7>(acc, f); mfma_cell<OMASK, 8>(acc, f);
 }
 
-template <int TAP, int I>
+template <int OMASK, int I>
+__device__ __forceinline__ void load_a1(Frag& f, const float* __restrict__ src, int a0) {
+  if constexpr (input_used<OMASK, I>()) f.a[I] = *reinterpret_cast<const f32x4*>(src + a0 + I * (POS * ROW));
+}
+// this lane's activation operands of K group kg (address of cell 0; cell I is I*1024 floats further)
+template <int OMASK>
+__device__ __forceinline__ void load_a(Frag& f, const float* __restrict__ src, int pos, int quad, int kg) {
+  const int a0 = act_addr(0, pos, kg * 16 + quad * 4);
+  load_a1<OMASK, 0>(f, src, a0); load_a1<OMASK, 1>(f, src, a0); load_a1<OMASK, 2>(f, src, a0);
+  load_a1<OMASK, 3>(f, src, a0); load_a1<OMASK, 4>(f, src, a0); load_a1<OMASK, 5>(f, src, a0);
+  load_a1<OMASK, 6>(f, src, a0); load_a1<OMASK, 7>(f, src, a0); load_a1<OMASK, 8>(f, src, a0);
+}
+__device__ __forceinline__ void load_b(Frag& f, const float* __restrict__ w, int lane) {
+  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(w) + lane;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) f.b[t] = p[t * 64];
+}
+
+// All K groups of one job.  On entry f0.b holds the weights of the job's first K group; on
+// exit it holds those of the next job's first K group (`w_after`, may be null): the weight
+// stream is always one K group ahead, also across jobs and stage barriers.  Unrolled by two
+// so that the two operand sets swap roles without register copies.
+template <int OMASK>
+__device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], Frag& f0, Frag& f1, const float* __restrict__ src,
+                                          const float* __restrict__ w, int kgroups,
+                                          const float* __restrict__ w_after, int lane) {
+  const int pos = lane & 15, quad = lane >> 4;
+  int kg = 0;
+  for (; kg + 2 <= kgroups; kg += 2) {
+    load_b(f1, w + (kg + 1) * W_KG_FLOATS, lane);
+    load_a<OMASK>(f0, src, pos, quad, kg);
+    load_a<OMASK>(f1, src, pos, quad, kg + 1);
+    mfma_group<OMASK>(acc, f0);
+    const float* w_nxt = (kg + 2 < kgroups) ? w + (kg + 2) * W_KG_FLOATS : w_after;
+    if (w_nxt != nullptr) load_b(f0, w_nxt, lane);
+    mfma_group<OMASK>(acc, f1);
+  }
+  if (kg < kgroups) {                 // odd tail
+    if (w_after != nullptr) load_b(f1, w_after, lane);
+    load_a<OMASK>(f0, src, pos, quad, kg);
+    mfma_group<OMASK>(acc, f0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) f0.b[t] = f1.b[t];
+  }
+}
+
+template <int OMASK, int TAP, int I>
 __device__ __forceinline__ void mfma_extra_pair(f32x4 (&acc)[CELLS], const float (&ax)[CELLS], const float (&bx)[9]) {
-  if constexpr (TapMap<I, TAP>::valid) {
+  if constexpr (pair_used<OMASK, I, TAP>()) {
     constexpr int o = TapMap<I, TAP>::o;
     acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[I], bx[TAP], acc[o], 0, 0, 0);
   }
 }
-template <int TAP>
+template <int OMASK, int TAP>
 __device__ __forceinline__ void mfma_extra_tap(f32x4 (&acc)[CELLS], const float (&ax)[CELLS], const float (&bx)[9]) {
-  mfma_extra_pair<TAP, 0>(acc, ax, bx); mfma_extra_pair<TAP, 1>(acc, ax, bx); mfma_extra_pair<TAP, 2>(acc, ax, bx);
-  mfma_extra_pair<TAP, 3>(acc, ax, bx); mfma_extra_pair<TAP, 4>(acc, ax, bx); mfma_extra_pair<TAP, 5>(acc, ax, bx);
-  mfma_extra_pair<TAP, 6>(acc, ax, bx); mfma_extra_pair<TAP, 7>(acc, ax, bx); mfma_extra_pair<TAP, 8>(acc, ax, bx);
+  mfma_extra_pair<OMASK, TAP, 0>(acc, ax, bx); mfma_extra_pair<OMASK, TAP, 1>(acc, ax, bx);
+  mfma_extra_pair<OMASK, TAP, 2>(acc, ax, bx); mfma_extra_pair<OMASK, TAP, 3>(acc, ax, bx);
+  mfma_extra_pair<OMASK, TAP, 4>(acc, ax, bx); mfma_extra_pair<OMASK, TAP, 5>(acc, ax, bx);
+  mfma_extra_pair<OMASK, TAP, 6>(acc, ax, bx); mfma_extra_pair<OMASK, TAP, 7>(acc, ax, bx);
+  mfma_extra_pair<OMASK, TAP, 8>(acc, ax, bx);
+}
+// the (<= 4) raw input planes as one extra K step (projection / recall conv)
+template <int OMASK>
+__device__ __forceinline__ void extra_planes(f32x4 (&acc)[CELLS], const float* __restrict__ wx,
+                                             const float* __restrict__ inp, int lane) {
+  float ax[CELLS], bx[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) bx[t] = wx[t * 64 + lane];
+#pragma unroll
+  for (int i = 0; i < CELLS; ++i) ax[i] = inp[(i * POS + (lane & 15)) * 4 + (lane >> 4)];
+  mfma_extra_tap<OMASK, 0>(acc, ax, bx); mfma_extra_tap<OMASK, 1>(acc, ax, bx); mfma_extra_tap<OMASK, 2>(acc, ax, bx);
+  mfma_extra_tap<OMASK, 3>(acc, ax, bx); mfma_extra_tap<OMASK, 4>(acc, ax, bx); mfma_extra_tap<OMASK, 5>(acc, ax, bx);
+  mfma_extra_tap<OMASK, 6>(acc, ax, bx); mfma_extra_tap<OMASK, 7>(acc, ax, bx); mfma_extra_tap<OMASK, 8>(acc, ax, bx);
 }
 
-
-// Run the layer program on the 16 positions whose input planes are in
-// `inp` ([cell][pos][4 planes]); `lds` holds the two activation buffers.  Every
-// thread of the 256-thread workgroup must call it.  Outputs: logits
-// [pos][policy_channels][9] and value [pos] for pos < n_valid (any address space).
-__device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, int n_layers,
-                                         const float* __restrict__ W, float* __restrict__ lds,
-                                         const float* __restrict__ inp, int policy_channels, int n_valid,
-                                         float* logits, float* value) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int pos = lane & 15;     // A row / C column owner
-  const int quad = lane >> 4;    // K slice / C row group
-  const int tile0 = 0;
-  const int count = n_valid;
-  for (int L = 0; L < n_layers; ++L) {
-    const NetLayer ly = prog->layers[L];
-    const float* __restrict__ src = lds + (ly.src & 1) * ACT_FLOATS;
-
-    for (int nt = wave; nt < ly.ntiles; nt += NET_WAVES) {
-      f32x4 acc[CELLS];
+// ---- epilogues: lane holds C[pos = 4*quad + r][cout = 16*nt + (lane & 15)] for the job's cells ----
+// ACT: 0 none, 1 relu, 2 tanh.  Output cell o lives o*1024 floats after cell 0, so the four
+// per-lane offsets are computed once and every access is base + constant.
+template <int OMASK, int ACT, bool RES>
+__device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], float* __restrict__ dst,
+                                             const float* res, int lane, int nt) {
+  const int quad = lane >> 4, cout = nt * 16 + (lane & 15);
+  int off[4];
 #pragma unroll
-      for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-      // main channels, 16 per group
-      const f32x4* __restrict__ wl = reinterpret_cast<const f32x4*>(W + ly.w_off);
-      for (int kg = 0; kg < ly.kgroups; ++kg) {
-        f32x4 av[CELLS], bw[9];
+  for (int r = 0; r < 4; ++r) off[r] = act_addr(0, quad * 4 + r, cout);
+  float v[CELLS][4];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) bw[t] = wl[((size_t)(t * ly.kgroups + kg) * ly.ntiles + nt) * 64 + lane];
+  for (int o = 0; o < CELLS; ++o)
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i)
-          av[i] = *reinterpret_cast<const f32x4*>(src + act_addr(i, pos, kg * 16 + quad * 4));
-        mfma_step<0>(acc, av, bw);
-        mfma_step<1>(acc, av, bw);
-        mfma_step<2>(acc, av, bw);
-        mfma_step<3>(acc, av, bw);
-      }
-      // the (<= 4) raw input planes as one extra K step (projection / recall conv)
-      if (ly.extra) {
-        float ax[CELLS], bx[9];
-        const float* __restrict__ wx = W + ly.wx_off;
+    for (int r = 0; r < 4; ++r) {
+      if (!((OMASK >> o) & 1)) continue;
+      v[o][r] = acc[o][r];
+      if constexpr (RES) v[o][r] += res[o * (POS * ROW) + off[r]];   // read before any write below
+    }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) bx[t] = wx[(size_t)(t * ly.ntiles + nt) * 64 + lane];
+  for (int o = 0; o < CELLS; ++o)
 #pragma unroll
-        for (int i = 0; i < CELLS; ++i) ax[i] = inp[(i * POS + pos) * 4 + quad];
-        mfma_extra_tap<0>(acc, ax, bx); mfma_extra_tap<1>(acc, ax, bx); mfma_extra_tap<2>(acc, ax, bx);
-        mfma_extra_tap<3>(acc, ax, bx); mfma_extra_tap<4>(acc, ax, bx); mfma_extra_tap<5>(acc, ax, bx);
-        mfma_extra_tap<6>(acc, ax, bx); mfma_extra_tap<7>(acc, ax, bx); mfma_extra_tap<8>(acc, ax, bx);
-      }
-
-      // ---- epilogue: lane holds C[pos = 4*quad + r][cout = 16*nt + (lane & 15)]
-      const int cout = nt * 16 + (lane & 15);
-      if (ly.dst < 2) {
-        float* __restrict__ dst = lds + ly.dst * ACT_FLOATS;
-        const float* __restrict__ res = ly.res >= 0 ? lds + ly.res * ACT_FLOATS : nullptr;
+    for (int r = 0; r < 4; ++r) {
+      if (!((OMASK >> o) & 1)) continue;
+      float x = v[o][r];
+      if constexpr (ACT == 1) x = fmaxf(x, 0.0f);
+      if constexpr (ACT == 2) x = tanhf(x);
+      dst[o * (POS * ROW) + off[r]] = x;
+    }
+}
+template <int OMASK>
+__device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob& job, float* __restrict__ lds,
+                                         int lane, int policy_channels, int n_valid, float* logits, float* value) {
+  const int quad = lane >> 4;
+  const int cout = job.nt * 16 + (lane & 15);
+  if (job.dst < NET_BUFFERS) {
+    float* dst = lds + job.dst * ACT_FLOATS;
+    if (job.res >= 0) {
+      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 1, true>(acc, dst, lds + job.res * ACT_FLOATS, lane, job.nt);
+    } else if (job.act == 1) {
+      epilogue_lds<OMASK, 1, false>(acc, dst, nullptr, lane, job.nt);
+    } else if (job.act == 2) {
+      epilogue_lds<OMASK, 2, false>(acc, dst, nullptr, lane, job.nt);
+    } else {
+      epilogue_lds<OMASK, 0, false>(acc, dst, nullptr, lane, job.nt);
+    }
+  } else if (job.dst == NET_BUFFERS) {        // policy logits [pos][P][9]
+    if (cout < policy_channels) {
 #pragma unroll
-        for (int o = 0; o < CELLS; ++o) {
+      for (int r = 0; r < 4; ++r) {
+        const int gp = quad * 4 + r;
+        if (gp < n_valid) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int a = act_addr(o, quad * 4 + r, cout);
-            float v = acc[o][r];
-            if (res != nullptr) v += res[a];
-            if (ly.act == 1) v = fmaxf(v, 0.0f);
-            else if (ly.act == 2) v = tanhf(v);
-            dst[a] = v;
-          }
+          for (int o = 0; o < CELLS; ++o)
+            if ((OMASK >> o) & 1) logits[((size_t)gp * policy_channels + cout) * CELLS + o] = acc[o][r];
         }
-      } else if (ly.dst == 2) {          // policy logits [B][P][9]
-        if (cout < policy_channels) {
+      }
+    }
+  } else {                                     // value: mean over (C=1,H,W), tanh (blocks.py:82-84)
+    if constexpr (OMASK == 0x1FF) {
+      if (cout == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gp = tile0 + quad * 4 + r;
-            if (gp < count) {
+        for (int r = 0; r < 4; ++r) {
+          const int gp = quad * 4 + r;
+          if (gp < n_valid) {
+            float s = 0.0f;
 #pragma unroll
-              for (int o = 0; o < CELLS; ++o)
-                logits[((size_t)gp * policy_channels + cout) * CELLS + o] = acc[o][r];
-            }
-          }
-        }
-      } else {                           // value: mean over (C=1,H,W), tanh (blocks.py:82-84)
-        if (cout == 0) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int gp = tile0 + quad * 4 + r;
-            if (gp < count) {
-              float s = 0.0f;
-#pragma unroll
-              for (int o = 0; o < CELLS; ++o) s += acc[o][r];
-              value[gp] = tanhf(s / 9.0f);
-            }
+            for (int o = 0; o < CELLS; ++o) s += acc[o][r];
+            value[gp] = tanhf(s / 9.0f);
           }
         }
       }
     }
-    __syncthreads();
+  }
+}
+
+// one job: K loop, input-plane step, epilogue
+template <int OMASK>
+__device__ __forceinline__ void run_job(const NetJob& job, Frag& f0, Frag& f1, const float* __restrict__ W,
+                                        const float* w_after, float* __restrict__ lds,
+                                        const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
+                                        float* logits, float* value) {
+  f32x4 acc[CELLS];
+#pragma unroll
+  for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+  job_kloop<OMASK>(acc, f0, f1, lds + job.src * ACT_FLOATS, W + job.w_off, job.kgroups, w_after, lane);
+  if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
+  epilogue<OMASK>(acc, job, lds, lane, policy_channels, n_valid, logits, value);
+}
+
+// Run the compiled network on the 16 positions whose input planes are in `inp`
+// ([cell][pos][4 planes]); `lds` holds the activation buffers.  Every thread of
+// the 256-thread workgroup must call it; it ends with a workgroup barrier.
+// Outputs: logits [pos][policy_channels][9] and value [pos] for pos < n_valid
+// (any address space).
+// STAMPS (diagnostic build only): wave 0 adds up the shader-clock ticks it spends computing
+// jobs (K loops, input-plane step, epilogue) and waiting at stage barriers into stamps[0..1].
+template <bool STAMPS = false>
+__device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, const float* __restrict__ W,
+                                         float* __restrict__ lds, const float* __restrict__ inp,
+                                         int policy_channels, int n_valid, float* logits, float* value,
+                                         unsigned long long* stamps = nullptr) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const NetJob* __restrict__ jobs = prog->jobs[wave];
+  const int n_jobs = prog->n_jobs[wave];
+
+  // first K group of the first job after `j` that reads weights, or nullptr
+  auto weights_after = [&](int j) -> const float* {
+    for (int n = j + 1; n < n_jobs; ++n)
+      if (jobs[n].og != OG_NONE && jobs[n].kgroups > 0) return W + jobs[n].w_off;
+    return nullptr;
+  };
+
+  Frag f0, f1;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) f0.b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* w0 = weights_after(-1);
+    if (w0 != nullptr) load_b(f0, w0, lane);
+  }
+
+  unsigned long long tk[2] = {0, 0}, ts = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (STAMPS) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tk[slot] += now - ts;
+      ts = now;
+    }
+  };
+  if constexpr (STAMPS) ts = __builtin_amdgcn_s_memtime();
+
+  for (int j = 0; j < n_jobs; ++j) {
+    const NetJob job = jobs[j];
+    if (job.og != OG_NONE) {
+      const float* w_after = job.kgroups > 0 ? weights_after(j) : nullptr;
+      switch (job.og) {
+        case 0: run_job<og_mask(0)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+        case 1: run_job<og_mask(1)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+        case 2: run_job<og_mask(2)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+        case 3: run_job<og_mask(3)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+        default: run_job<og_mask(4)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+      }
+    }
+    stamp(0);
+    if (job.stage_end) __syncthreads();
+    stamp(1);
+  }
+  if constexpr (STAMPS) {
+    if (tid == 0) {
+      stamps[0] = tk[0];
+      stamps[1] = tk[1];
+      stamps[2] = 0;
+      stamps[3] = 0;
+    }
   }
 }
 

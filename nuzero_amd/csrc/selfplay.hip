@@ -7,6 +7,10 @@
 //               step the game, re-root and mix the next root's noise;
 //   net phase   the fused RecurrentNet forward for the 16 pending leaves on
 //               FP32 MFMA (net_dev.hpp), inputs and outputs in LDS.
+// A slot that finishes its game takes the next unplayed game of the round from a
+// global counter (the reference's ActorPool hands the next game to whichever
+// actor is free, Training/AlphaZero.py:525-577), so a round of n_games games
+// runs on n_slots concurrent trees.
 // A game's tree is only ever touched by its own row, so games progress through
 // their moves independently of each other: the whole
 // select -> inference -> expand -> backup -> move cycle (Training/Gamer.py:64-79
@@ -27,23 +31,29 @@
 namespace nz {
 namespace {
 
+// STAMPS = true is the diagnostic build: thread 0 of every workgroup adds up the
+// shader-clock ticks it spends in each phase ([block][4] = cycles of the loop,
+// tree ticks, net ticks, total ticks).  The product build carries no stamp.
+template <bool STAMPS>
 __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, const NetProgram* __restrict__ prog,
                                                                int n_layers, const float* __restrict__ W,
                                                                const double* __restrict__ noise,      // [G][T][A]
-                                                               const double* __restrict__ uniforms) { // [G][T][3]
-  __shared__ __attribute__((aligned(16))) float lds[2 * ACT_FLOATS + INP_FLOATS + POS * TTT_ACTIONS + POS];
-  float* const inp = lds + 2 * ACT_FLOATS;
+                                                               const double* __restrict__ uniforms,   // [G][T][3]
+                                                               unsigned long long* __restrict__ stamps) {
+  __shared__ __attribute__((aligned(16))) float lds[NET_LDS_FLOATS + POS * TTT_ACTIONS + POS];
+  float* const inp = lds + NET_BUFFERS * ACT_FLOATS;
   float* const out_logits = inp + INP_FLOATS;          // [16][9]
   float* const out_value = out_logits + POS * TTT_ACTIONS;
 
   const int tid = threadIdx.x;
   const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
   const int sub = tid & (LANES_PER_GAME - 1);
-  const int g = blockIdx.x * POS + slot;
+  const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
+  int g = gslot;                                       // game being played in this slot
 
   // per-game state, identical on the 16 lanes of a row (except my_node)
-  bool alive = g < p.n_games;
-  const Arena t = arena_of(p, alive ? g : 0);
+  bool alive = gslot < p.n_slots && g < p.n_games;
+  const Arena t = arena_of(p, gslot < p.n_slots ? gslot : 0);
   int root = 0, node_count = 1, sims_left = p.sims, move = 0;
   uint32_t board = 0u;
   int n_sim = 0, n_exp = 0, n_lvl = 0, n_kid = 0;
@@ -51,6 +61,8 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
   int my_node = 0, path_len = 0, leaf = 0;
   uint32_t leaf_sb = 0u, leaf_meta = 0u;
   int outcome = 0;
+  unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0;
+  if constexpr (STAMPS) t_begin = t0 = __builtin_amdgcn_s_memtime();
 
   for (;;) {
     // ------------------------------ tree phase ---------------------------------
@@ -61,13 +73,34 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
         const double value = (double)out_value[slot];
         node_count = expand_row(p, t, leaf, leaf_meta, leaf_sb, prob, sub, node_count);
         backup_row(t, my_node, path_len, value, sub);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        row_memory_fence();
         --sims_left;
         ++n_sim;
         ++n_exp;
         pending = false;
       }
       while (alive && !pending) {
+        if (move < 0) {
+          // ---- the slot's game is over: record it, take the next one of the round ----
+          if (sub == 0) {
+            p.length[g] = -move - 1;
+            p.outcome[g] = outcome;
+            p.sim_count[g] = n_sim;
+            p.exp_count[g] = n_exp;
+            p.sel_nodes[g] = n_lvl;
+            p.sel_children[g] = n_kid;
+          }
+          int ng = 0;
+          if (sub == 0) ng = atomicAdd(p.next_game, 1);
+          ng = row_geti(ng, 0);
+          if (ng >= p.n_games) { alive = false; break; }
+          g = ng;
+          if (sub == 0) arena_reset(t);
+          row_memory_fence();
+          root = 0; node_count = 1; sims_left = p.sims; move = 0; board = 0u; outcome = 0;
+          n_sim = n_exp = n_lvl = n_kid = 0;
+          continue;
+        }
         if (sims_left == 0) {
           // ---- the move is searched: act, step, re-root (Gamer.py:71-79) ----------
           int chosen = -1, new_root = root, term = 0, new_children = 0;
@@ -83,24 +116,24 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           term = row_geti(term, 0);
           new_children = row_geti(new_children, 0);
           new_board = (uint32_t)row_geti((int)new_board, 0);
-          if (chosen < 0) { alive = false; break; }        // error flag already raised
+          if (chosen < 0) { alive = false; break; }        // error flag already raised (whole round fails)
           board = new_board;
           root = new_root;
           ++move;
           sims_left = p.sims;
           if (term != 0) {
-            alive = false;
             outcome = term_value(term);
-            break;
+            move = -move - 1;                               // game over after `move` moves
+            continue;
           }
           if (p.training) {
             if (new_children != TTT_ACTIONS - move) {       // the host's draw-count assumption failed
               if (sub == 0) p.desync[g] = 1;
-              alive = false;
-              break;
+              move = -move - 1;                             // abandon; the lock-step route replays it
+              continue;
             }
             noise_row(p, t, root, noise + ((size_t)g * TTT_MAX_MOVES + move) * TTT_ACTIONS, sub);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            row_memory_fence();
           }
           continue;
         }
@@ -112,7 +145,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           if (sub == 0)
             t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
           backup_row(t, my_node, d.path_len, (double)term_value(term), sub);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          row_memory_fence();
           --sims_left;
           ++n_sim;
           continue;
@@ -123,7 +156,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           const double value = (double)row[9];
           node_count = expand_row(p, t, d.node, d.lk.y, d.sb, prob, sub, node_count);
           backup_row(t, my_node, d.path_len, value, sub);
-          __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+          row_memory_fence();
           --sims_left;
           ++n_sim;
           ++n_exp;
@@ -146,37 +179,53 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       }
       *reinterpret_cast<float4*>(inp + (sub * POS + slot) * 4) = v;
     }
-    if (!__syncthreads_or(pending ? 1 : 0)) break;
+    const int any_pending = __syncthreads_or(pending ? 1 : 0);
+    if constexpr (STAMPS) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      t_tree += t1 - t0;
+      t0 = t1;
+    }
+    if (!any_pending) break;
 
     // ------------------------------ net phase ----------------------------------
-    net_tile(prog, n_layers, W, lds, inp, 1, POS, out_logits, out_value);
+    net_tile(prog, W, lds, inp, 1, POS, out_logits, out_value);
     // net_tile ends with a barrier: outputs are visible to every row
+    if constexpr (STAMPS) {
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      t_net += t1 - t0;
+      t0 = t1;
+      ++n_cycles;
+    }
+  }
+  if constexpr (STAMPS) {
+    if (tid == 0) {
+      stamps[blockIdx.x * 4 + 0] = n_cycles;
+      stamps[blockIdx.x * 4 + 1] = t_tree;
+      stamps[blockIdx.x * 4 + 2] = t_net;
+      stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
   }
 
-  if (g < p.n_games && sub == 0) {
-    p.board[g] = board;
-    p.length[g] = move;
-    p.alive[g] = 0;
-    p.outcome[g] = outcome;
-    p.root[g] = root;
-    p.node_count[g] = node_count;
-    p.sims_left[g] = sims_left;
-    p.pending[g] = -1;
-    p.n_root_children[g] = 0;
-    p.sim_count[g] = n_sim;
-    p.exp_count[g] = n_exp;
-    p.sel_nodes[g] = n_lvl;
-    p.sel_children[g] = n_kid;
+  if (gslot < p.n_slots && sub == 0) {
+    p.alive[gslot] = 0;
+    p.pending[gslot] = -1;
+    p.n_root_children[gslot] = 0;
   }
 }
 
 }  // namespace
 
+int selfplay_blocks(int n_slots) { return (n_slots + POS - 1) / POS; }
+
 void launch_selfplay(const TreeParams& p, const NetProgram* prog_dev, int n_layers, const float* weights,
-                     const double* noise, const double* uniforms, hipStream_t s) {
-  const int blocks = (p.n_games + POS - 1) / POS;
-  hipLaunchKernelGGL(selfplay_kernel, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights, noise,
-                     uniforms);
+                     const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s) {
+  const int blocks = selfplay_blocks(p.n_slots);
+  if (stamps != nullptr)
+    hipLaunchKernelGGL(selfplay_kernel<true>, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights,
+                       noise, uniforms, stamps);
+  else
+    hipLaunchKernelGGL(selfplay_kernel<false>, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights,
+                       noise, uniforms, stamps);
 }
 
 }  // namespace nz

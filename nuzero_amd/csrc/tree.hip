@@ -18,25 +18,29 @@ __global__ void reset_kernel(TreeParams p) {
     p.leaf_count[1] = 0;
     *p.error_flag = 0;
   }
-  if (g >= p.n_games) return;
-  arena_reset(arena_of(p, g));
-  p.board[g] = 0u;
-  p.length[g] = 0;
-  p.alive[g] = 1;
-  p.outcome[g] = 0;
-  p.root[g] = 0;
-  p.node_count[g] = 1;
-  p.sims_left[g] = p.sims;
-  p.pending[g] = -1;
-  p.leaf_board[g] = 0u;
-  p.path_len[g] = 0;
-  p.sim_count[g] = 0;
-  p.exp_count[g] = 0;
-  p.sel_nodes[g] = 0;
-  p.sel_children[g] = 0;
-  p.n_root_children[g] = 0;
-  p.desync[g] = 0;
-  hist_clear(p, g);
+  if (g == 0) *p.next_game = p.n_slots < p.n_games ? p.n_slots : p.n_games;
+  if (g < p.n_games) p.alive[g] = g < p.n_slots ? 1 : 0;
+  if (g < p.n_slots) {          // per-slot state
+    arena_reset(arena_of(p, g));
+    p.board[g] = 0u;
+    p.root[g] = 0;
+    p.node_count[g] = 1;
+    p.sims_left[g] = p.sims;
+    p.pending[g] = -1;
+    p.leaf_board[g] = 0u;
+    p.path_len[g] = 0;
+    p.n_root_children[g] = 0;
+  }
+  if (g < p.n_games) {          // per-game records
+    p.length[g] = 0;
+    p.outcome[g] = 0;
+    p.sim_count[g] = 0;
+    p.exp_count[g] = 0;
+    p.sel_nodes[g] = 0;
+    p.sel_children[g] = 0;
+    p.desync[g] = 0;
+    hist_clear(p, g);
+  }
 }
 
 __global__ __launch_bounds__(BLOCK) void noise_kernel(TreeParams p, const double* __restrict__ noise) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
       const double value = (double)p.leaf_value[pend];
       node_count = expand_row(p, t, leaf, t.link[leaf].y, sb, prob, sub, node_count);
       backup_row(t, my_node, path_len, value, sub);
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+      row_memory_fence();
       --sims_left;
       ++n_sim;
       ++n_exp;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
         if (sub == 0)
           t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
         backup_row(t, my_node, d.path_len, (double)term_value(term), sub);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        row_memory_fence();
         --sims_left;
         ++n_sim;
         continue;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
         const double value = (double)row[9];
         node_count = expand_row(p, t, d.node, d.lk.y, d.sb, prob, sub, node_count);
         backup_row(t, my_node, d.path_len, value, sub);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        row_memory_fence();
         --sims_left;
         ++n_sim;
         ++n_exp;
@@ -205,7 +209,8 @@ __global__ void export_moves_kernel(TreeParams p, int32_t* visits, int32_t* acti
 }  // namespace
 
 void launch_reset(const TreeParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(reset_kernel, dim3((p.n_games + 255) / 256), dim3(256), 0, s, p);
+  const int n = p.n_games > p.n_slots ? p.n_games : p.n_slots;
+  hipLaunchKernelGGL(reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
 }
 void launch_noise(const TreeParams& p, const double* noise, hipStream_t s) {
   const int blocks = (p.n_games + GAMES_PER_BLOCK - 1) / GAMES_PER_BLOCK;

@@ -90,6 +90,12 @@ __device__ __forceinline__ float row_softmax9(float logit, int sub) {
   return e / s;
 }
 
+// A game tree is only ever read and written by the lanes of its own row, i.e. by one
+// wavefront, and a wavefront's memory operations take effect in program order: ordering
+// a simulation's stores before the next simulation's loads needs no wait, only that the
+// compiler keeps the order.
+__device__ __forceinline__ void row_memory_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
 struct Arena {
   int32_t* visit;
   double* value_sum;
@@ -150,6 +156,29 @@ __device__ __forceinline__ void backup_row(const Arena& t, int my_node, int path
 // One descent from `root` (Explorer.py:51-58).  On return `node`/`lk` is the
 // leaf and its link word, `sb` the scratch position there, `path_len` the
 // number of nodes on the path and lane i's `my_node` is path node i.
+// rotate a value by N lanes inside its 16-lane row (DPP row_ror: no LDS round trip)
+template <int N>
+__device__ __forceinline__ int row_ror(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+  return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
+}
+// one butterfly step of the row-wide max over (score, key); key = action << 8 | lane
+template <int N>
+__device__ __forceinline__ void argmax_step(double& score, int& key) {
+  const double os = row_ror<N>(score);
+  const int ok = row_ror<N>(key);
+  if (os > score || (os == score && ok > key)) {
+    score = os;
+    key = ok;
+  }
+}
+
+// One descent from `root` (Explorer.py:51-58).  On return `node`/`lk` is the
+// leaf and its link word, `sb` the scratch position there, `path_len` the
+// number of nodes on the path and lane i's `my_node` is path node i.
 struct Descent {
   int node;
   uint2 lk;
@@ -167,12 +196,12 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
   d.children = 0;
   if (sub == 0) my_node = root;
   d.lk = t.link[root];
+  int n_parent = t.visit[root];     // below the root it is carried down from the chosen child
   while (meta_children(d.lk.y) != 0u) {
     const int k = (int)meta_children(d.lk.y);
     const int base = (int)d.lk.x;
     ++d.levels;
     d.children += k;
-    const int n_parent = t.visit[d.node];
     if (n_parent >= p.tab_len) {
       if (sub == 0) atomicOr(p.error_flag, 2);
       break;
@@ -181,12 +210,12 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
     const double cb = p.bias_tab[n_parent];
     const bool negate = (int)meta_to_play(d.lk.y) == p.negate_player;
     double score = -INFINITY;
-    int action = -1;
-    int child = base;
+    int key = -1;
+    int n = 0;
     uint2 clk = make_uint2(0u, 0u);
     if (sub < k) {
-      child = base + sub;
-      const int n = t.visit[child];
+      const int child = base + sub;
+      n = t.visit[child];
       const double vs = t.value_sum[child];
       const double pr = t.prior[child];
       clk = t.link[child];
@@ -197,24 +226,21 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
       if (negate) q = -q;
       q = q * p.value_factor;
       score = conf + q;
-      action = (int)meta_action(clk.y);
+      key = ((int)meta_action(clk.y) << 8) | sub;
     }
     // max over (score, action): the larger action wins a tie (Explorer.py:100)
-#pragma unroll
-    for (int w = 8; w >= 1; w >>= 1) {
-      const double os = __shfl_xor(score, w, LANES_PER_GAME);
-      const int oa = __shfl_xor(action, w, LANES_PER_GAME);
-      const int oc = __shfl_xor(child, w, LANES_PER_GAME);
-      const uint32_t ox = __shfl_xor(clk.x, w, LANES_PER_GAME);
-      const uint32_t oy = __shfl_xor(clk.y, w, LANES_PER_GAME);
-      if (os > score || (os == score && oa > action)) {
-        score = os; action = oa; child = oc; clk.x = ox; clk.y = oy;
-      }
-    }
-    d.sb = ttt_step(d.sb, action);
-    d.node = child;
+    argmax_step<8>(score, key);
+    argmax_step<4>(score, key);
+    argmax_step<2>(score, key);
+    argmax_step<1>(score, key);
+    const int win = key & 0xff;
+    clk.x = (uint32_t)row_geti((int)clk.x, win);
+    clk.y = (uint32_t)row_geti((int)clk.y, win);
+    n_parent = row_geti(n, win);
+    d.sb = ttt_step(d.sb, key >> 8);
+    d.node = base + win;
     d.lk = clk;
-    if (sub == d.path_len) my_node = child;
+    if (sub == d.path_len) my_node = d.node;
     ++d.path_len;
   }
   return d;

@@ -26,7 +26,7 @@ class SelfPlayEngine:
     argument of the reference's ``Explorer(search_config, training)``.
     """
 
-    def __init__(self, search_config, n_games, training=True, device=0, negate_player=2):
+    def __init__(self, search_config, n_games, training=True, device=0, negate_player=2, n_slots=None):
         if not torch.cuda.is_available():
             raise RuntimeError("nuzero_amd needs a ROCm GPU; there is no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -36,10 +36,12 @@ class SelfPlayEngine:
         game = _lib.GameDesc(game=_lib.NZ_GAME_TIC_TAC_TOE, negate_player=negate_player)
         self._h = c_void_p(0)
         with torch.cuda.device(self.device):
-            check(lib.nz_engine_create(byref(self._h), byref(cfg), byref(game), int(n_games), int(device)))
+            check(lib.nz_engine_create_ex(byref(self._h), byref(cfg), byref(game),
+                                          int(n_slots if n_slots else n_games), int(n_games), int(device)))
         d = _lib.Dims()
         check(lib.nz_engine_dims(self._h, byref(d)), self._h)
         self.n_games, self.num_actions, self.max_moves = d.n_games, d.num_actions, d.max_moves
+        self.n_slots = d.n_slots
         self.state_shape = (d.state_channels, d.rows, d.cols)
         self.node_capacity = d.node_capacity
         self.net_spec = None
@@ -95,6 +97,18 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             check(lib.nz_net_forward(self._h, _ptr(x), b, _ptr(logits), _ptr(value), _ptr(probs), _stream()), self._h)
         return logits, value, probs
+
+    def net_forward_stamps(self, states):
+        """Diagnostic build: mean ticks wave 0 of a workgroup spends computing jobs / waiting at barriers."""
+        x = torch.as_tensor(states, dtype=torch.float32).to(self.device).contiguous()
+        b = x.shape[0]
+        logits = torch.empty((b, 9), dtype=torch.float32, device=self.device)
+        value = torch.empty((b,), dtype=torch.float32, device=self.device)
+        out = (c_double * 4)()
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.device(self.device):
+            check(lib.nz_net_forward_stamps(self._h, _ptr(x), b, _ptr(logits), _ptr(value), out), self._h)
+        return dict(zip(("jobs", "barriers"), list(out)[:2]))
 
     # ---- stepping --------------------------------------------------------------
     def reset(self):
@@ -231,6 +245,17 @@ class SelfPlayEngine:
     # ---- kernel timing -----------------------------------------------------------
     def profile(self, enable=True):
         check(lib.nz_engine_profile(self._h, int(enable)), self._h)
+
+    def phase_stamps(self, enable, read=False):
+        """Select (or deselect) the stamped diagnostic build of the persistent kernel;
+        with read=True return the last stamped run's phase shares first."""
+        out = (c_double * 8)()
+        check(lib.nz_engine_phase_stamps(self._h, int(enable), out if read else None), self._h)
+        if read:
+            return {"cycles_per_workgroup": out[0], "tree_share": out[1], "net_share": out[2],
+                    "mean_over_max_lifetime": out[3], "net_ticks_per_cycle": out[4],
+                    "tree_ticks_per_cycle": out[5], "max_workgroup_ticks": out[6], "workgroups": out[7]}
+        return None
 
     def profile_read(self):
         ms = (c_double * 3)()

@@ -8,9 +8,9 @@ from conftest import full_table
 pytestmark = pytest.mark.gpu
 
 
-def _engine(config, n_games, training=True):
+def _engine(config, n_games, training=True, n_slots=None):
     from nuzero_amd.engine import SelfPlayEngine
-    return SelfPlayEngine(config, n_games, training=training)
+    return SelfPlayEngine(config, n_games, training=training, n_slots=n_slots)
 
 
 def _images(codes):
@@ -124,6 +124,22 @@ def test_network_batch_slot_invariance(net_kat):
     l2, v2, _ = eng.net_forward(x[7:8])
     assert np.array_equal(l0.cpu().numpy()[7:8], l2.cpu().numpy())
     eng.close()
+
+
+@pytest.mark.parametrize("n_slots", [16, 20, 1])
+def test_round_larger_than_concurrency(search_kat, net_kat, n_slots):
+    """A round of 48 games on fewer concurrent slots: finished slots take the
+    next game of the round; every game still equals the reference's."""
+    for case_name in ("legacy100_A", "explore50_B"):
+        case = search_kat[case_name]
+        games = case["games"]
+        eng = _engine(case["config"], len(games), training=True, n_slots=n_slots)
+        assert eng.n_slots == n_slots and eng.n_games == len(games)
+        eng.set_table(full_table(net_kat, case["table"]))
+        eng.play(base_seed=games[0]["seed"])
+        _compare_with_reference_games(eng.export(trace=True), games)
+        assert eng.live_games() == 0
+        eng.close()
 
 
 def test_eval_mode_persistent(search_kat, net_kat):
