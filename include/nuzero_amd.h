@@ -207,8 +207,8 @@ nz_status nz_net_forward(nz_engine* e, const float* states_dev, int32_t batch, f
                          float* value_dev, float* probs_dev, void* stream);
 
 /* Diagnostic build of the network kernel: mean shader-clock ticks wave 0 of a
- * workgroup spends [0] computing its jobs (K loops, input-plane step, epilogue),
- * [1] waiting at the stage barriers; [2], [3] reserved.  Synchronises. */
+ * workgroup spends in [0] the K-group loops (LDS reads + MFMA), [1] the
+ * input-plane step, [2] the epilogues, [3] at the stage barriers.  Synchronises. */
 nz_status nz_net_forward_stamps(nz_engine* e, const float* states_dev, int32_t batch, float* logits_dev,
                                 float* value_dev, double* ticks4_host);
 
@@ -225,9 +225,10 @@ nz_status nz_engine_profile_read(nz_engine* e, double* ms_host /*[3]*/, int64_t*
  * [0] mean tree/net cycles per workgroup, [1] share of ticks in the tree phase,
  * [2] share in the network phase, [3] mean / max workgroup lifetime (how evenly
  * the workgroups finish), [4] shader-clock ticks per network phase, [5] per tree
- * phase, [6] ticks of the longest-lived workgroup, [7] workgroups.  Run times of
- * the stamped build are not quoted. */
-nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out8_host);
+ * phase, [6] ticks of the longest-lived workgroup, [7] workgroups, [8] wave 0's
+ * ticks per cycle in end-of-move bookkeeping, [9] in the pending expansion.  Run
+ * times of the stamped build are not quoted. */
+nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out10_host);
 
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream

@@ -71,6 +71,7 @@ struct TreeParams {
   int32_t training;
   int32_t softmax_moves;
   double eps_softmax, eps_random;
+  int32_t sims_per_cycle;  // persistent kernel: simulations a game may run between two network passes
   int32_t* error_flag;
   // per-move records, [G][T]...
   uint32_t* hist_board;
@@ -104,6 +105,7 @@ void launch_selfplay(const TreeParams& p, const struct NetProgram* prog_dev, int
 struct NetJob {
   int32_t w_off;       // float offset of this (layer, n-tile)'s packed main weights [kgroup][tap][lane][4]
   int32_t wx_off;      // float offset of its packed input-plane weights [tap][lane]
+  int32_t next_w_off;  // w_off of the next job of this wave that reads weights, or -1 (prefetch target)
   int16_t kgroups;     // 16-channel K groups read from the source activation buffer
   int16_t nt;          // output tile: channels 16 nt .. 16 nt + 15
   int8_t extra;        // 1: also read the (<= 4) input planes as one extra K step
@@ -119,6 +121,7 @@ constexpr int NET_MAX_JOBS = 192;
 constexpr int OG_NONE = 7;
 struct NetProgram {
   int32_t n_jobs[NET_WAVES_HOST];
+  int32_t first_w_off[NET_WAVES_HOST];   // w_off of each wave's first weight-reading job, or -1
   NetJob jobs[NET_WAVES_HOST][NET_MAX_JOBS];
 };
 

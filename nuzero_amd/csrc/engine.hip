@@ -294,7 +294,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   A(bias_tab, e->tab_len); A(sqrt_tab, e->tab_len);
   A(e->d_noise, G * TTT_ACTIONS); A(e->d_uniforms, G * 3);
   A(e->d_game_noise, GTA); A(e->d_game_uniforms, GT * 3);
-  A(e->d_stamps, (size_t)selfplay_blocks(n_slots) * 4);
+  A(e->d_stamps, (size_t)selfplay_blocks(n_slots) * 6);
   A(p.next_game, 1);
   A(e->prog_dev, 1);
 #undef A
@@ -314,6 +314,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   p.softmax_moves = cfg->number_of_softmax_moves;
   p.eps_softmax = cfg->epsilon_softmax_exploration;
   p.eps_random = cfg->epsilon_random_exploration;
+  p.sims_per_cycle = 16;
 
   // Explorer.calculate_exploration_bias / calculate_ucb_factor (Explorer.py:103-112):
   // log() and sqrt() of the parent visit count, from the host libm
@@ -451,6 +452,14 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   stage({{vh + 2, cur, side, -1, vact, true}});
   stage({{vh + 3, side, 4, -1, 0, false}});                                 // mean over cells needs all nine
   if (!ok) return fail(e, NZ_ERR_ARG, "network too deep for one fused launch (%d iterations)", recurrent_iterations);
+  for (int w = 0; w < NET_WAVES_HOST; ++w) {     // prefetch chain: each job names the next weight stream
+    int32_t next = -1;
+    for (int j = pg.n_jobs[w] - 1; j >= 0; --j) {
+      pg.jobs[w][j].next_w_off = next;
+      if (pg.jobs[w][j].og != OG_NONE && pg.jobs[w][j].kgroups > 0) next = pg.jobs[w][j].w_off;
+    }
+    pg.first_w_off[w] = next;
+  }
   e->algorithmic_flops_per_position = flops;
 
   if (e->weights_dev) { (void)hipFree(e->weights_dev); e->weights_dev = nullptr; }
@@ -730,7 +739,7 @@ nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out4_host
   if (!e) return NZ_ERR_ARG;
   if (out4_host) {
     const int blocks = selfplay_blocks(e->n_slots);
-    std::vector<unsigned long long> h((size_t)blocks * 4);
+    std::vector<unsigned long long> h((size_t)blocks * 6);
     NZ_HIP(e, hipSetDevice(e->device));
     NZ_HIP(e, hipDeviceSynchronize());
     NZ_HIP(e, hipMemcpy(h.data(), e->d_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -748,6 +757,13 @@ nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out4_host
     out4_host[5] = sum[1] / std::max(sum[0], 1.0);   // shader-clock ticks per tree phase
     out4_host[6] = max_total;                        // ticks of the longest-lived workgroup
     out4_host[7] = (double)blocks;
+    double fin = 0, exp = 0;
+    for (int b = 0; b < blocks; ++b) {
+      fin += (double)h[(size_t)blocks * 4 + b * 2];
+      exp += (double)h[(size_t)blocks * 4 + b * 2 + 1];
+    }
+    out4_host[8] = fin / std::max(sum[0], 1.0);      // wave 0: ticks per cycle in end-of-move bookkeeping
+    out4_host[9] = exp / std::max(sum[0], 1.0);      // wave 0: ticks per cycle in the pending expansion
   }
   e->stamps = enable != 0;
   return NZ_OK;

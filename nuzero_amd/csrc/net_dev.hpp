@@ -263,17 +263,20 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
 }
 
 // one job: K loop, input-plane step, epilogue
-template <int OMASK>
+template <int OMASK, typename Stamp>
 __device__ __forceinline__ void run_job(const NetJob& job, Frag& f0, Frag& f1, const float* __restrict__ W,
                                         const float* w_after, float* __restrict__ lds,
                                         const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
-                                        float* logits, float* value) {
+                                        float* logits, float* value, Stamp&& stamp) {
   f32x4 acc[CELLS];
 #pragma unroll
   for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
   job_kloop<OMASK>(acc, f0, f1, lds + job.src * ACT_FLOATS, W + job.w_off, job.kgroups, w_after, lane);
+  stamp(0);
   if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
+  stamp(1);
   epilogue<OMASK>(acc, job, lds, lane, policy_channels, n_valid, logits, value);
+  stamp(2);
 }
 
 // Run the compiled network on the 16 positions whose input planes are in `inp`
@@ -281,8 +284,8 @@ __device__ __forceinline__ void run_job(const NetJob& job, Frag& f0, Frag& f1, c
 // the 256-thread workgroup must call it; it ends with a workgroup barrier.
 // Outputs: logits [pos][policy_channels][9] and value [pos] for pos < n_valid
 // (any address space).
-// STAMPS (diagnostic build only): wave 0 adds up the shader-clock ticks it spends computing
-// jobs (K loops, input-plane step, epilogue) and waiting at stage barriers into stamps[0..1].
+// STAMPS (diagnostic build only): wave 0 adds up the shader-clock ticks it spends in the K
+// loops, the input-plane step, the epilogues and at the stage barriers into stamps[0..3].
 template <bool STAMPS = false>
 __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, const float* __restrict__ W,
                                          float* __restrict__ lds, const float* __restrict__ inp,
@@ -294,22 +297,12 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   const NetJob* __restrict__ jobs = prog->jobs[wave];
   const int n_jobs = prog->n_jobs[wave];
 
-  // first K group of the first job after `j` that reads weights, or nullptr
-  auto weights_after = [&](int j) -> const float* {
-    for (int n = j + 1; n < n_jobs; ++n)
-      if (jobs[n].og != OG_NONE && jobs[n].kgroups > 0) return W + jobs[n].w_off;
-    return nullptr;
-  };
-
   Frag f0, f1;
 #pragma unroll
   for (int t = 0; t < 9; ++t) f0.b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* w0 = weights_after(-1);
-    if (w0 != nullptr) load_b(f0, w0, lane);
-  }
+  if (prog->first_w_off[wave] >= 0) load_b(f0, W + prog->first_w_off[wave], lane);
 
-  unsigned long long tk[2] = {0, 0}, ts = 0;
+  unsigned long long tk[4] = {0, 0, 0, 0}, ts = 0;
   auto stamp = [&](int slot) {
     if constexpr (STAMPS) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -322,26 +315,22 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   for (int j = 0; j < n_jobs; ++j) {
     const NetJob job = jobs[j];
     if (job.og != OG_NONE) {
-      const float* w_after = job.kgroups > 0 ? weights_after(j) : nullptr;
+      const float* w_after = (job.kgroups > 0 && job.next_w_off >= 0) ? W + job.next_w_off : nullptr;
       switch (job.og) {
-        case 0: run_job<og_mask(0)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
-        case 1: run_job<og_mask(1)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
-        case 2: run_job<og_mask(2)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
-        case 3: run_job<og_mask(3)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
-        default: run_job<og_mask(4)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value); break;
+        case 0: run_job<og_mask(0)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 1: run_job<og_mask(1)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 2: run_job<og_mask(2)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 3: run_job<og_mask(3)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        default: run_job<og_mask(4)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
       }
     }
-    stamp(0);
+    stamp(2);
     if (job.stage_end) __syncthreads();
-    stamp(1);
+    stamp(3);
   }
   if constexpr (STAMPS) {
-    if (tid == 0) {
-      stamps[0] = tk[0];
-      stamps[1] = tk[1];
-      stamps[2] = 0;
-      stamps[3] = 0;
-    }
+    if (tid == 0)
+      for (int i = 0; i < 4; ++i) stamps[i] = tk[i];
   }
 }
 

@@ -17,6 +17,10 @@
 // around Search/Explorer.py:40-67) stays on the GPU.  With 4096 games the grid is
 // 256 workgroups, one per CU.
 //
+// A game runs at most sims_per_cycle simulations between two network passes: late in a game
+// most simulations end in terminal positions, and one such row would otherwise hold the other
+// fifteen (and the matrix pipes) for dozens of simulations; it simply skips a pass instead.
+//
 // Randomness.  The reference's draws per move (gamma x n_root_children, two
 // uniforms, at most one more inside np.random.choice; SURVEY.md appendix A rule
 // 13) come from a per-game host stream.  The host pre-draws every move's values
@@ -58,28 +62,43 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
   uint32_t board = 0u;
   int n_sim = 0, n_exp = 0, n_lvl = 0, n_kid = 0;
   bool pending = false;
-  int my_node = 0, path_len = 0, leaf = 0;
+  int my_node = 0, path_len = 0, leaf = 0, my_n = 0, win0 = -1;
+  double my_vs = 0.0;
   uint32_t leaf_sb = 0u, leaf_meta = 0u;
+  RootCache rc;
+  root_cache_load(rc, t, 0, sub);
   int outcome = 0;
-  unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0;
+  unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0, t_expand = 0;
   if constexpr (STAMPS) t_begin = t0 = __builtin_amdgcn_s_memtime();
 
+  __shared__ int s_max_sims;
+  unsigned long long crit_sims = 0;
   for (;;) {
     // ------------------------------ tree phase ---------------------------------
+    int cyc_sims = 0;
+    if constexpr (STAMPS) {
+      if (tid == 0) s_max_sims = 0;
+      __syncthreads();
+    }
     if (alive) {
+      unsigned long long te0 = 0;
+      if constexpr (STAMPS) te0 = __builtin_amdgcn_s_memtime();
       if (pending) {
         const float logit = sub < 9 ? out_logits[slot * TTT_ACTIONS + sub] : 0.0f;
         const float prob = row_softmax9(logit, sub);
         const double value = (double)out_value[slot];
         node_count = expand_row(p, t, leaf, leaf_meta, leaf_sb, prob, sub, node_count);
-        backup_row(t, my_node, path_len, value, sub);
+        backup_cached(t, rc, my_node, my_n, my_vs, path_len, value, sub, win0);
         row_memory_fence();
+        if (path_len <= 2) root_cache_load(rc, t, root, sub);   // the root or one of its children got children
         --sims_left;
+        ++cyc_sims;
         ++n_sim;
         ++n_exp;
         pending = false;
       }
-      while (alive && !pending) {
+      if constexpr (STAMPS) t_expand += __builtin_amdgcn_s_memtime() - te0;
+      while (alive && !pending && cyc_sims < p.sims_per_cycle) {
         if (move < 0) {
           // ---- the slot's game is over: record it, take the next one of the round ----
           if (sub == 0) {
@@ -98,6 +117,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           if (sub == 0) arena_reset(t);
           row_memory_fence();
           root = 0; node_count = 1; sims_left = p.sims; move = 0; board = 0u; outcome = 0;
+          root_cache_load(rc, t, root, sub);
           n_sim = n_exp = n_lvl = n_kid = 0;
           continue;
         }
@@ -105,6 +125,8 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           // ---- the move is searched: act, step, re-root (Gamer.py:71-79) ----------
           int chosen = -1, new_root = root, term = 0, new_children = 0;
           uint32_t new_board = board;
+          unsigned long long tf0 = 0;
+          if constexpr (STAMPS) tf0 = __builtin_amdgcn_s_memtime();
           if (sub == 0) {
             const MoveResult r = finish_move_one(p, t, g, root, board, move,
                                                  uniforms ? uniforms + ((size_t)g * TTT_MAX_MOVES + move) * 3 : nullptr);
@@ -116,6 +138,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           term = row_geti(term, 0);
           new_children = row_geti(new_children, 0);
           new_board = (uint32_t)row_geti((int)new_board, 0);
+          if constexpr (STAMPS) t_finish += __builtin_amdgcn_s_memtime() - tf0;
           if (chosen < 0) { alive = false; break; }        // error flag already raised (whole round fails)
           board = new_board;
           root = new_root;
@@ -135,18 +158,20 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
             noise_row(p, t, root, noise + ((size_t)g * TTT_MAX_MOVES + move) * TTT_ACTIONS, sub);
             row_memory_fence();
           }
+          root_cache_load(rc, t, root, sub);
           continue;
         }
-        const Descent d = descend_row(p, t, root, board, sub, my_node);
+        const Descent d = descend_cached(p, t, rc, root, board, sub, my_node, my_n, my_vs, win0);
         n_lvl += d.levels;
         n_kid += d.children;
         const int term = ttt_terminal(d.sb);
         if (term != 0) {
           if (sub == 0)
             t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
-          backup_row(t, my_node, d.path_len, (double)term_value(term), sub);
+          backup_cached(t, rc, my_node, my_n, my_vs, d.path_len, (double)term_value(term), sub, win0);
           row_memory_fence();
           --sims_left;
+          ++cyc_sims;
           ++n_sim;
           continue;
         }
@@ -155,9 +180,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
           const float prob = sub < 9 ? row[sub] : 0.0f;
           const double value = (double)row[9];
           node_count = expand_row(p, t, d.node, d.lk.y, d.sb, prob, sub, node_count);
-          backup_row(t, my_node, d.path_len, value, sub);
+          backup_cached(t, rc, my_node, my_n, my_vs, d.path_len, value, sub, win0);
           row_memory_fence();
+          if (d.path_len <= 2) root_cache_load(rc, t, root, sub);
           --sims_left;
+          ++cyc_sims;
           ++n_sim;
           ++n_exp;
           continue;
@@ -179,13 +206,19 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       }
       *reinterpret_cast<float4*>(inp + (sub * POS + slot) * 4) = v;
     }
+    if constexpr (STAMPS) {
+      if (sub == 0) atomicMax(&s_max_sims, cyc_sims);
+    }
+    const int any_alive = __syncthreads_or(alive ? 1 : 0);
     const int any_pending = __syncthreads_or(pending ? 1 : 0);
     if constexpr (STAMPS) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       t_tree += t1 - t0;
       t0 = t1;
+      crit_sims += (unsigned long long)s_max_sims;
     }
-    if (!any_pending) break;
+    if (!any_alive) break;
+    if (!any_pending) continue;       // every live row used up its simulations for this cycle
 
     // ------------------------------ net phase ----------------------------------
     net_tile(prog, W, lds, inp, 1, POS, out_logits, out_value);
@@ -203,6 +236,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       stamps[blockIdx.x * 4 + 1] = t_tree;
       stamps[blockIdx.x * 4 + 2] = t_net;
       stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+    // wave 0's own time inside move bookkeeping and inside pending expansions (subset of tree ticks)
+    if (tid == 0) {
+      stamps[gridDim.x * 4 + blockIdx.x * 2 + 0] = t_finish;
+      stamps[gridDim.x * 4 + blockIdx.x * 2 + 1] = crit_sims;   // sum over cycles of the slowest row's simulations
     }
   }
 

@@ -246,6 +246,140 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
   return d;
 }
 
+// ---- root-resident variant (persistent kernel) ---------------------------------
+// Every simulation starts at the root, so the persistent kernel keeps the root's
+// statistics and, in lane j, those of root child j in registers for the whole
+// move: level 0 of each descent then needs no memory access, and because every
+// selection also hands the chosen child's (visit, value_sum) to the lane that
+// owns that path node, the backup is a plain store.  Memory stays current
+// (write-through), so the end-of-move code and the lock-step kernels read the
+// same values.  The arithmetic is the one of descend_row / backup_row.
+struct RootCache {
+  int k, base;           // children of the root (k = 0: not expanded yet)
+  int root_n;
+  double root_vs;
+  uint32_t root_meta;
+  int n;                 // lane j < k: child j
+  double vs, pr;
+  uint2 lk;
+};
+__device__ __forceinline__ void root_cache_load(RootCache& c, const Arena& t, int root, int sub) {
+  const uint2 lk = t.link[root];
+  c.k = (int)meta_children(lk.y);
+  c.base = (int)lk.x;
+  c.root_meta = lk.y;
+  c.root_n = t.visit[root];
+  c.root_vs = t.value_sum[root];
+  c.n = 0;
+  c.vs = 0.0;
+  c.pr = 0.0;
+  c.lk = make_uint2(0u, 0u);
+  if (sub < c.k) {
+    const int child = c.base + sub;
+    c.n = t.visit[child];
+    c.vs = t.value_sum[child];
+    c.pr = t.prior[child];
+    c.lk = t.link[child];
+  }
+}
+// PUCT score of one child (Explorer.py:103-130), shared by both descents
+__device__ __forceinline__ double puct_score(const TreeParams& p, double sq, double cb, bool negate, int n, double vs,
+                                             double pr) {
+  const double u = sq / (double)(n + 1);
+  double conf = pr * u;
+  conf = conf * cb;
+  double q = (n == 0) ? 0.0 : vs / (double)n;
+  if (negate) q = -q;
+  q = q * p.value_factor;
+  return conf + q;
+}
+// As descend_row; additionally lane i receives path node i's (visit, value_sum) as read
+// during the descent (my_n, my_vs) and win0 is the lane of the chosen root child (-1: none).
+__device__ __forceinline__ Descent descend_cached(const TreeParams& p, const Arena& t, const RootCache& c, int root,
+                                                  uint32_t board, int sub, int& my_node, int& my_n, double& my_vs,
+                                                  int& win0) {
+  Descent d;
+  d.node = root;
+  d.sb = board;
+  d.path_len = 1;
+  d.levels = 0;
+  d.children = 0;
+  d.lk = make_uint2((uint32_t)c.base, c.root_meta);
+  win0 = -1;
+  if (sub == 0) {
+    my_node = root;
+    my_n = c.root_n;
+    my_vs = c.root_vs;
+  }
+  int n_parent = c.root_n;
+  while (meta_children(d.lk.y) != 0u) {
+    const int k = (int)meta_children(d.lk.y);
+    const int base = (int)d.lk.x;
+    ++d.levels;
+    d.children += k;
+    if (n_parent >= p.tab_len) {
+      if (sub == 0) atomicOr(p.error_flag, 2);
+      break;
+    }
+    const double sq = p.sqrt_tab[n_parent];
+    const double cb = p.bias_tab[n_parent];
+    const bool negate = (int)meta_to_play(d.lk.y) == p.negate_player;
+    double score = -INFINITY;
+    int key = -1;
+    int n = 0;
+    double vs = 0.0;
+    uint2 clk = make_uint2(0u, 0u);
+    if (sub < k) {
+      double pr;
+      if (d.path_len == 1) {          // children of the root: registers
+        n = c.n; vs = c.vs; pr = c.pr; clk = c.lk;
+      } else {
+        const int child = base + sub;
+        n = t.visit[child];
+        vs = t.value_sum[child];
+        pr = t.prior[child];
+        clk = t.link[child];
+      }
+      score = puct_score(p, sq, cb, negate, n, vs, pr);
+      key = ((int)meta_action(clk.y) << 8) | sub;
+    }
+    argmax_step<8>(score, key);
+    argmax_step<4>(score, key);
+    argmax_step<2>(score, key);
+    argmax_step<1>(score, key);
+    const int win = key & 0xff;
+    if (d.path_len == 1) win0 = win;
+    clk.x = (uint32_t)row_geti((int)clk.x, win);
+    clk.y = (uint32_t)row_geti((int)clk.y, win);
+    n_parent = row_geti(n, win);
+    const double vs_win = row_get(vs, win);
+    d.sb = ttt_step(d.sb, key >> 8);
+    d.node = base + win;
+    d.lk = clk;
+    if (sub == d.path_len) {
+      my_node = d.node;
+      my_n = n_parent;
+      my_vs = vs_win;
+    }
+    ++d.path_len;
+  }
+  return d;
+}
+// Explorer.backpropagate without loads: lane i stores path node i from the values the descent read
+__device__ __forceinline__ void backup_cached(const Arena& t, RootCache& c, int my_node, int my_n, double my_vs,
+                                              int path_len, double value, int sub, int win0) {
+  if (sub < path_len) {
+    t.visit[my_node] = my_n + 1;
+    t.value_sum[my_node] = my_vs + value;
+  }
+  c.root_n += 1;
+  c.root_vs = c.root_vs + value;
+  if (path_len >= 2 && sub == win0) {
+    c.n += 1;
+    c.vs = c.vs + value;
+  }
+}
+
 // Root noise (Explorer.py:201-210): lane j mixes child j's prior.
 __device__ __forceinline__ void noise_row(const TreeParams& p, const Arena& t, int root, const double* noise_row9,
                                           int sub) {

@@ -108,7 +108,7 @@ class SelfPlayEngine:
         torch.cuda.synchronize(self.device)
         with torch.cuda.device(self.device):
             check(lib.nz_net_forward_stamps(self._h, _ptr(x), b, _ptr(logits), _ptr(value), out), self._h)
-        return dict(zip(("jobs", "barriers"), list(out)[:2]))
+        return dict(zip(("k_loops", "input_planes", "epilogues", "barriers"), list(out)))
 
     # ---- stepping --------------------------------------------------------------
     def reset(self):
@@ -249,12 +249,13 @@ class SelfPlayEngine:
     def phase_stamps(self, enable, read=False):
         """Select (or deselect) the stamped diagnostic build of the persistent kernel;
         with read=True return the last stamped run's phase shares first."""
-        out = (c_double * 8)()
+        out = (c_double * 10)()
         check(lib.nz_engine_phase_stamps(self._h, int(enable), out if read else None), self._h)
         if read:
             return {"cycles_per_workgroup": out[0], "tree_share": out[1], "net_share": out[2],
                     "mean_over_max_lifetime": out[3], "net_ticks_per_cycle": out[4],
-                    "tree_ticks_per_cycle": out[5], "max_workgroup_ticks": out[6], "workgroups": out[7]}
+                    "tree_ticks_per_cycle": out[5], "max_workgroup_ticks": out[6], "workgroups": out[7],
+                    "finish_move_ticks_per_cycle": out[8], "critical_sims_per_cycle": out[9]}
         return None
 
     def profile_read(self):

@@ -1,4 +1,5 @@
-import sys, time; sys.path.insert(0, '/root/repo')
+import sys, time; import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from nuzero_amd.engine import SelfPlayEngine
 from nuzero_amd.weights import synthetic_recurrent_net_weights
