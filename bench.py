@@ -1,20 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the self-play hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--sims S]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--round R] [--sims S]
 
-A "step" is one self-play round: G concurrent Tic-Tac-Toe games per GPU played
-to the end with S MCTS simulations per move, network fused into the search
-(BASELINE.json configs[1]: 100 sims/move, 4096 concurrent games, 1 x MI355X),
-followed -- when N > 1 -- by the RCCL gather of the finished games to rank 0's
-replay buffer.  Weights are synthetic (random-init RecurrentNet(2,1,64,2), seed
-0); games need no dataset.  Prints ONE JSON line on rank 0.
+A "step" is one self-play round on one GPU: R Tic-Tac-Toe games played to the
+end on G concurrent game trees (slots that finish a game take the next one, as
+the reference's ActorPool does), S MCTS simulations per move, network fused
+into the search (BASELINE.json configs[1]: 100 sims/move, 4096 concurrent games,
+1 x MI355X; default R = 4 G), followed -- when N > 1 -- by the RCCL gather of the
+finished games to rank 0's replay buffer.  Weights are synthetic (random-init
+RecurrentNet(2,1,64,2), seed 0); games need no dataset.  Prints ONE JSON line on
+rank 0.
 
-Extra keys: `expansions_per_s`, `simulations_per_s` (the metric's second half),
-`roofline` for the dominant kernel (the fused network kernel, FP32 MFMA),
-`roofline_select` for the tree kernel (HBM), `cpu_baseline` = the CPU oracle
-(oracle/search.py + oracle/net.py, the restatement of the reference's
-Explorer/Gamer path) timed on this box's host cores on a bounded sample.
+Extra keys
+  expansions_per_s, simulations_per_s   the metric's second half
+  roofline          the dominant kernel: the persistent self-play kernel, priced
+                    against the FP32 MFMA peak with the network's algorithmic
+                    FLOPs (in-bounds taps only) over the kernel's HIP-event time
+  roofline_net      the fused network kernel alone (4096 positions per launch)
+  roofline_select   the lock-step tree kernel (select + expand + backup) against
+                    HBM, SURVEY.md 8(d) byte counts
+  phases            in-kernel shader-clock shares of the stamped diagnostic build
+  cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the
+                    restatement of the reference's Explorer/Gamer path) timed on
+                    this box's host cores on a bounded sample
 """
 import argparse
 import json
@@ -61,14 +70,17 @@ def cpu_baseline(sims, seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--games", type=int, default=4096, help="concurrent games per GPU")
+    ap.add_argument("--games", type=int, default=4096, help="concurrent games (slots) per GPU")
+    ap.add_argument("--round", type=int, default=0, help="games per self-play round per GPU (default 4 x --games)")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--iters", type=int, default=2, help="recurrent iterations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel measurements after the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    n_round = args.round if args.round > 0 else 4 * args.games
 
     import torch
     from nuzero_amd.engine import SelfPlayEngine
@@ -87,8 +99,9 @@ def main():
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = legacy_ttt_search_config(args.sims)
-    eng = SelfPlayEngine(cfg, args.games, training=True, device=local_rank)
-    eng.set_weights(synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True), recurrent_iterations=args.iters)
+    weights = synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True)
+    eng = SelfPlayEngine(cfg, n_round, training=True, device=local_rank, n_slots=args.games)
+    eng.set_weights(weights, recurrent_iterations=args.iters)
     gather = nzdist.ReplayGather(eng, world, rank) if world > 1 else None
 
     def barrier():
@@ -97,8 +110,8 @@ def main():
         torch.cuda.synchronize()
 
     def step(i):
-        # game g of rank r in round i gets its own stream seed
-        eng.play(base_seed=(i * world + rank) * args.games)
+        # every game of every rank and round has its own stream seed
+        eng.play(base_seed=(i * world + rank) * n_round)
         if gather is not None:
             gather.gather()
 
@@ -112,7 +125,7 @@ def main():
         c = eng.counters()
         sims_total += c["simulations"]
         exp_total += c["expansions"]
-        games_total += args.games
+        games_total += n_round
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -123,46 +136,75 @@ def main():
         dt = float(tmax[0])
         sims_total, exp_total, games_total = float(t[1]), float(t[2]), float(t[3])
 
-    # ---- per-kernel timing, HIP events on the engine's stream (one more round, not in `value`)
-    eng.profile(True)
-    eng.play(base_seed=10 ** 6 + rank * args.games)
-    prof = eng.profile_read()
-    eng.profile(False)
-    pc = eng.counters()
-    flops_pos = eng.net_flops_per_position()
-    net_ms, net_n = prof["network"]["ms"], prof["network"]["launches"]
-    tree_ms, tree_n = prof["tree_advance"]["ms"], prof["tree_advance"]["launches"]
-    achieved_tf = pc["expansions"] * flops_pos / (net_ms * 1e-3) / 1e12 if net_ms > 0 else 0.0
-    # select/backup algorithmic bytes: 11 + 20 k bytes per internal node whose k
-    # children are scored, 24 bytes per path node backed up (path = levels + 1 per simulation)
-    sel_bytes = (11 * pc["select_nodes"] + 20 * pc["select_children"]
-                 + 24 * (pc["select_nodes"] + pc["simulations"]))
-    sel_gbs = sel_bytes / (tree_ms * 1e-3) / 1e9 if tree_ms > 0 else 0.0
+    out = {
+        "metric": "self-play games/sec (+ MCTS node-expansions/sec), Tic-Tac-Toe %d sims/move" % args.sims,
+        "value": games_total / dt, "unit": "games/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Tic_Tac_Toe, %d sims/move, %d concurrent self-play games per GPU (%d games per "
+                               "round), RecurrentNet(2,1,64,2) %d recurrent iterations f32, tree statistics f64, "
+                               "legacy TTT search config" % (args.sims, args.games, n_round, args.iters),
+                   "concurrent_games_per_gpu": args.games, "games_per_round_per_gpu": n_round,
+                   "sims_per_move": args.sims,
+                   "parallelism": "games sharded by rank, 1 RCCL gather per round" if world > 1 else "1 GPU"},
+        "expansions_per_s": exp_total / dt, "simulations_per_s": sims_total / dt,
+    }
+
+    if not args.no_extras:
+        flops_pos = eng.net_flops_per_position()
+        # ---- dominant kernel: HIP events around the persistent kernel, on its own stream, one more round
+        eng.profile(True)
+        eng.play(base_seed=10 ** 6 + rank * n_round)
+        prof = eng.profile_read()
+        eng.profile(False)
+        pc = eng.counters()
+        k_ms, k_n = prof["search"]["ms"], prof["search"]["launches"]
+        achieved = pc["expansions"] * flops_pos / (k_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
+            "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(k_n, 1),
+            "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n}
+        # ---- in-kernel phase shares (stamped diagnostic build; its run time is not quoted)
+        eng.phase_stamps(True)
+        eng.play(base_seed=2 * 10 ** 6 + rank * n_round)
+        out["phases"] = eng.phase_stamps(False, read=True)
+        # ---- the network kernel alone
+        x = (torch.rand((4096, 2, 3, 3), device="cuda") > 0.6).float()
+        eng.net_forward(x, want_probs=False)
+        torch.cuda.synchronize()
+        eng.profile(True)
+        for _ in range(20):
+            eng.net_forward(x, want_probs=False)
+        pn = eng.profile_read()["network"]
+        eng.profile(False)
+        net_tf = 20 * 4096 * flops_pos / (pn["ms"] * 1e-3) / 1e12
+        out["roofline_net"] = {"bound": "mfma", "kernel": "net_kernel (fused RecurrentNet forward, 4096 positions)",
+                               "achieved": net_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": net_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_us": pn["ms"] * 1e3 / 20}
+        # ---- the lock-step tree kernel against HBM (SURVEY.md 8d bytes: 11 + 20 k per scored node,
+        #      24 per path node backed up)
+        ls = SelfPlayEngine(cfg, args.games, training=True, device=local_rank)
+        ls.set_weights(weights, recurrent_iterations=args.iters)
+        ls.play_lockstep(base_seed=0)
+        ls.profile(True)
+        ls.play_lockstep(base_seed=args.games)
+        pl = ls.profile_read()["search"]
+        ls.profile(False)
+        lc = ls.counters()
+        sel_bytes = 11 * lc["select_nodes"] + 20 * lc["select_children"] + 24 * (lc["select_nodes"] + lc["simulations"])
+        sel_gbs = sel_bytes / (pl["ms"] * 1e-3) / 1e9
+        out["roofline_select"] = {"bound": "hbm", "kernel": "advance_kernel (lock-step select + expand + backup)",
+                                  "achieved": sel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": sel_gbs / HBM_PEAK_GBS, "traffic": None,
+                                  "bytes_per_launch": sel_bytes / max(pl["launches"], 1),
+                                  "avg_launch_us": pl["ms"] * 1e3 / max(pl["launches"], 1), "launches": pl["launches"]}
+        ls.close()
 
     if rank == 0:
-        out = {
-            "metric": "self-play games/sec (+ MCTS node-expansions/sec), Tic-Tac-Toe %d sims/move" % args.sims,
-            "value": games_total / dt, "unit": "games/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Tic_Tac_Toe, %d sims/move, %d concurrent self-play games per GPU, "
-                                   "RecurrentNet(2,1,64,2) %d recurrent iterations, legacy TTT search config"
-                                   % (args.sims, args.games, args.iters),
-                       "games_per_gpu": args.games, "sims_per_move": args.sims,
-                       "parallelism": "games sharded by rank, 1 RCCL gather/round" if world > 1 else "1 GPU"},
-            "expansions_per_s": exp_total / dt, "simulations_per_s": sims_total / dt,
-            "roofline": {"bound": "mfma", "kernel": "net_kernel (fused RecurrentNet forward, FP32 MFMA)",
-                         "achieved": achieved_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(net_n, 1),
-                         "avg_launch_us": net_ms * 1e3 / max(net_n, 1), "launches": net_n},
-            "roofline_select": {"bound": "hbm", "kernel": "advance_kernel (select + expand + backup)",
-                                "achieved": sel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": sel_gbs / HBM_PEAK_GBS, "traffic": None,
-                                "avg_launch_us": tree_ms * 1e3 / max(tree_n, 1), "launches": tree_n},
-            "kernel_ms_per_round": {k: v["ms"] for k, v in prof.items()},
-        }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -214,7 +214,8 @@ nz_status nz_net_forward_stamps(nz_engine* e, const float* states_dev, int32_t b
 
 /* Timing of the engine's own kernels, measured with HIP events on the stream
  * the kernels run on.  Enable, run, then read: total milliseconds and launch
- * count per kernel class (0 = tree advance, 1 = network, 2 = move/noise/export). */
+ * count per kernel class (0 = search: the persistent self-play kernel or the lock-step
+ * advance kernel, 1 = stand-alone network kernel, 2 = move/noise/reset/export). */
 nz_status nz_engine_profile(nz_engine* e, int32_t enable);
 nz_status nz_engine_profile_read(nz_engine* e, double* ms_host /*[3]*/, int64_t* launches_host /*[3]*/,
                                  int64_t* net_positions_host);

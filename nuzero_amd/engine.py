@@ -263,5 +263,5 @@ class SelfPlayEngine:
         n = (c_int64 * 3)()
         pos = c_int64(0)
         check(lib.nz_engine_profile_read(self._h, ms, n, byref(pos)), self._h)
-        names = ("tree_advance", "network", "move_misc")
+        names = ("search", "network", "move_misc")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}

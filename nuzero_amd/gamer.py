@@ -1,0 +1,147 @@
+"""Gamer with the reference's surface (Training/Gamer.py:17-104), without Ray.
+
+One reference Gamer plays one game per `play_game()` call on one CPU process;
+here one Gamer drives a GPU engine that plays `num_games` games per call on
+`concurrent_games` trees.  What comes back is what the reference's loop hands to
+the trainer and the replay buffer:
+
+* per game a record with ``state_history`` / ``get_state_from_history`` /
+  ``make_target`` / ``length`` -- the attributes ReplayBuffer.save_game reads
+  (Training/ReplayBuffer.py:31-33) -- and the six statistics of Gamer.py:42-50;
+* states are CPU float32 ``[1,C,H,W]`` tensors, policies flat lists of floats,
+  values numbers, as Training/AlphaZero.py:851-852,892-903 requires.
+"""
+import numpy as np
+import torch
+
+from .engine import SelfPlayEngine
+from .network import Network_Manager
+
+
+class GameRecord:
+    """The finished game as ReplayBuffer.save_game and the trainer see it."""
+
+    def __init__(self, states, visits, actions, length, terminal_value):
+        self.length = int(length)
+        self.terminal_value = int(terminal_value)
+        self.state_history = [torch.from_numpy(np.ascontiguousarray(states[m:m + 1])) for m in range(self.length)]
+        # tic_tac_toe.py:177-182: visit / sum(visits) for the root's children, 0 elsewhere
+        self.child_policy = []
+        for m in range(self.length):
+            v = [int(x) for x in visits[m]]
+            total = sum(v)
+            self.child_policy.append([x / total if x else 0 for x in v])
+        self.action_history = [int(a) for a in actions[:self.length]]
+
+    def get_state_from_history(self, i):
+        return self.state_history[i]
+
+    def make_target(self, i):
+        return (self.terminal_value, self.child_policy[i])
+
+    def get_length(self):
+        return self.length
+
+    def get_terminal_value(self):
+        return self.terminal_value
+
+
+class DisabledCache:
+    """Cache-shaped object for callers that expect one back from play_game
+    (AlphaZero.py:553-568); the engine evaluates every leaf."""
+
+    def get_hit_ratio(self):
+        return 0.0
+
+    def length(self):
+        return 0
+
+    def get_fill_ratio(self):
+        return 0.0
+
+    def get_update_threshold(self):
+        return 1.0
+
+    def update(self, other):
+        return None
+
+
+def game_stats(r, g):
+    """The statistics dict of Gamer.py:42-50,81-92 for game g of an export."""
+    n = int(r["lengths"][g])
+    ts = r["tree_size"][g, :n].astype(np.int64)
+    ch = r["n_children"][g, :n].astype(np.int64)
+    bias = r["bias"][g, :n]
+    acc = 0.0
+    for b in bias:                       # the reference accumulates in move order
+        acc += float(b)
+    return {"number_of_moves": n,
+            "average_children": int(ch.sum()) / n,
+            "average_tree_size": int(ts.sum()) / n,
+            "final_tree_size": int(ts[-1]),
+            "average_bias_value": acc / n,
+            "final_bias_value": float(bias[-1])}
+
+
+class Gamer:
+    def __init__(self, buffer, shared_storage, game_class, game_args, game_index, search_config,
+                 recurrent_iterations, cache_choice="disabled", size_estimate=10000,
+                 num_games=1, concurrent_games=None, device=0, base_seed=0):
+        """Arguments up to `size_estimate` are the reference's (Gamer.py:20).
+        `shared_storage` is anything with ``get()`` returning a Network_Manager (or
+        the Network_Manager itself); `buffer` anything with ``save_game(game, i)``
+        or None.  `game_class` must be Tic_Tac_Toe (by name) in this release."""
+        name = getattr(game_class, "__name__", str(game_class)).lower()
+        if "tic" not in name and "ttt" not in name:
+            raise NotImplementedError(f"game {name!r}: only Tic_Tac_Toe runs on the GPU engine so far")
+        if cache_choice not in ("disabled", None):
+            raise NotImplementedError("inference caches are not used by the GPU engine (cache_choice='disabled')")
+        self.buffer, self.shared_storage = buffer, shared_storage
+        self.game_index = game_index
+        self.search_config = search_config
+        self.recurrent_iterations = recurrent_iterations
+        self.num_games = num_games
+        self.base_seed = base_seed
+        self.time_to_stop = False
+        self.engine = SelfPlayEngine(search_config, num_games, training=True, device=device,
+                                     n_slots=concurrent_games or num_games)
+        self._loaded = None
+
+    def _network(self):
+        nm = self.shared_storage.get() if hasattr(self.shared_storage, "get") else self.shared_storage
+        if not isinstance(nm, Network_Manager):
+            nm = Network_Manager(nm)
+        return nm
+
+    def play_games(self):
+        """One self-play round: `num_games` games.  Returns (records, stats list)."""
+        nm = self._network() if self.shared_storage is not None else None
+        if nm is not None and self._loaded is not nm:
+            s = nm.spec()
+            self.engine.set_weights(nm.state_dict(), width=s.width, num_blocks=s.num_blocks, recall=s.recall,
+                                    value_activation=s.value_activation,
+                                    recurrent_iterations=self.recurrent_iterations)
+            self._loaded = nm
+        self.engine.play(base_seed=self.base_seed)
+        self.base_seed += self.num_games
+        r = self.engine.export()
+        records = [GameRecord(r["states"][g], r["visits"][g], r["actions"][g], r["lengths"][g], r["outcomes"][g])
+                   for g in range(self.num_games)]
+        stats = [game_stats(r, g) for g in range(self.num_games)]
+        if self.buffer is not None:
+            for rec in records:
+                self.buffer.save_game(rec, self.game_index)
+        return records, stats
+
+    def play_game(self, cache=None):
+        """Reference signature (Gamer.py:39-97): (stats, cache).  With num_games > 1
+        the stats are those of the round's first game; use play_games for all."""
+        _, stats = self.play_games()
+        return stats[0], DisabledCache()
+
+    def play_forever(self):
+        while not self.time_to_stop:
+            self.play_games()
+
+    def stop(self):
+        self.time_to_stop = True

@@ -229,3 +229,48 @@ def test_fused_search_equals_oracle_on_same_evaluations(sims, n_games, net, rout
             assert r["child_value_sum"][g, m][mv["child_actions"]].tolist() == mv["child_value_sums"]
     assert counters["expansions"] == n_exp
     eng.close()
+
+
+def test_gamer_surface_matches_reference(search_kat, net_kat):
+    """The Gamer-shaped adapter: records, targets and the six statistics must be
+    what the reference's Gamer.play_game hands to ReplayBuffer / the trainer."""
+    import torch
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.replay_buffer import ReplayBuffer
+
+    class tic_tac_toe:      # the game class is only identified by name
+        pass
+
+    case = search_kat["legacy100_A"]
+    games = case["games"]
+    rb = ReplayBuffer(window_size=1000, batch_size=8)
+    gamer = Gamer(rb, None, tic_tac_toe, [], 3, case["config"], 2, "disabled", num_games=len(games),
+                  concurrent_games=16, base_seed=games[0]["seed"])
+    gamer.engine.set_table(full_table(net_kat, "A"))
+    records, stats = gamer.play_games()
+    for rec, st, ref in zip(records, stats, games):
+        assert rec.length == ref["length"] and rec.terminal_value == ref["terminal_value"]
+        for i in range(rec.length):
+            s = rec.get_state_from_history(i)
+            assert s.dtype == torch.float32 and tuple(s.shape) == (1, 2, 3, 3) and not s.is_cuda
+            assert s.reshape(-1).int().tolist() == ref["states"][i]
+            v, pol = rec.make_target(i)
+            assert [v] + [float(x) for x in pol] == ref["targets"][i]
+        assert {k: float(v) for k, v in st.items()} == ref["stats"]
+    assert rb.len() == sum(g["length"] for g in games) and rb.played_games() == len(games)
+    state, (value, policy), idx = rb.get_buffer()[0]
+    assert idx == 3 and len(policy) == 9
+    gamer.engine.close()
+
+
+def test_network_manager_inference(net_kat):
+    """Network_Manager.inference on the GPU == the reference's outputs (1e-5)."""
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    nm = Network_Manager(synthetic_recurrent_net_weights(2, 2, 1, 16, 2, True, 2.0))
+    assert nm.is_recurrent() and nm.spec().width == 16
+    codes = net_kat["codes"][net_kat["sub_index"]]
+    p, v = nm.inference(_images(codes), False, 16)
+    assert tuple(p.shape) == (len(codes), 1, 3, 3) and tuple(v.shape) == (len(codes), 1)
+    np.testing.assert_allclose(p.cpu().numpy().reshape(-1, 9), net_kat["C_i16_logits"], atol=2e-6)
+    np.testing.assert_allclose(v.cpu().numpy().reshape(-1), net_kat["C_i16_value"], atol=1e-5)

@@ -1,0 +1,138 @@
+"""Host-side pieces that need no GPU: replay buffer window, payload packing, the
+world_size-2 gather over gloo, search-config conversion."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Rec:
+    def __init__(self, n, tag):
+        self.state_history = [torch.full((1, 2, 3, 3), float(tag * 100 + i)) for i in range(n)]
+        self.n, self.tag = n, tag
+
+    def get_state_from_history(self, i):
+        return self.state_history[i]
+
+    def make_target(self, i):
+        return (self.tag, [i / 9.0] * 9)
+
+
+def test_replay_buffer_window():
+    """Training/ReplayBuffer.py:24-36: the window counts games, but once full one
+    oldest POSITION is dropped per position added."""
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(window_size=2, batch_size=4)
+    rb.save_game(_Rec(5, 1), 0)
+    rb.save_game(_Rec(7, 2), 0)
+    assert rb.len() == 12 and rb.played_games() == 2
+    rb.save_game(_Rec(3, 3), 1)          # full: 3 in, 3 oldest out
+    assert rb.len() == 12 and rb.played_games() == 2
+    firsts = [float(e[0].flatten()[0]) for e in rb.get_buffer()]
+    assert firsts[0] == 103.0 and firsts[-1] == 302.0
+    state, (value, policy), idx = rb.get_buffer()[-1]
+    assert state.shape == (1, 2, 3, 3) and state.dtype == torch.float32 and value == 3 and len(policy) == 9 and idx == 1
+    batch = rb.get_sample(4, False, [])
+    assert len(batch) == 4
+    assert len(rb.get_slice(2, 5)) == 3
+
+
+def test_search_config_struct():
+    from nuzero_amd.search_config import legacy_ttt_search_config, to_struct
+    c = to_struct(legacy_ttt_search_config(25), True)
+    assert (c.mcts_simulations, c.keep_subtree, c.training) == (25, 1, 1)
+    assert (c.pb_c_base, c.pb_c_init, c.root_dist_alpha, c.root_exploration_fraction) == (5000.0, 1.15, 0.15, 0.2)
+    bad = legacy_ttt_search_config()
+    bad["Exploration"]["root_exploration_distribution"] = "dirichlet"
+    with pytest.raises(ValueError):
+        to_struct(bad, True)
+
+
+def _payload(rank, g=6, t=9, a=9):
+    rs = np.random.RandomState(rank)
+    return {
+        "states": torch.from_numpy(rs.rand(g, t, 2, 3, 3).astype(np.float32)),
+        "visits": torch.from_numpy(rs.randint(0, 100, (g, t, a)).astype(np.int32)),
+        "actions": torch.from_numpy(rs.randint(-1, 9, (g, t)).astype(np.int32)),
+        "lengths": torch.from_numpy(rs.randint(5, 10, (g,)).astype(np.int32)),
+        "outcomes": torch.from_numpy(rs.randint(-1, 2, (g,)).astype(np.int32)),
+        "tree_size": torch.from_numpy(rs.randint(0, 900, (g, t)).astype(np.int32)),
+        "n_children": torch.from_numpy(rs.randint(0, 9, (g, t)).astype(np.int32)),
+        "bias": torch.from_numpy(rs.rand(g, t)),
+    }
+
+
+def test_pack_unpack_roundtrip():
+    from nuzero_amd import dist as nzdist
+    p = _payload(3)
+    buf, layout = nzdist.pack(p)
+    assert buf.dtype == torch.uint8 and buf.numel() % 16 == 0
+    q = nzdist.unpack(buf, layout)
+    for k in nzdist.FIELDS:
+        assert q[k].dtype == p[k].dtype and torch.equal(q[k], p[k])
+
+
+def _gather_worker(rank, world, port, ret):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    from nuzero_amd import dist as nzdist
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = nzdist.gather_payload(_payload(rank), world, rank, dst=0)
+        if rank == 0:
+            ok = True
+            for k in nzdist.FIELDS:
+                want = torch.cat([_payload(r)[k] for r in range(world)], 0)
+                ok = ok and torch.equal(got[k], want)
+            ret["ok"] = ok
+        else:
+            ret[f"none{rank}"] = got is None
+        assert nzdist.shard_seeds(1000, 512, rank) == 1000 + 512 * rank
+    finally:
+        td.destroy_process_group()
+
+
+def test_gather_world_size_2_gloo():
+    """The once-per-round collection of finished games, two ranks on CPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get("ok") is True and ret.get("none1") is True
+
+
+def test_game_record_contract():
+    """What ReplayBuffer.save_game and AlphaZero.batch_update_weights touch."""
+    from nuzero_amd.gamer import GameRecord, game_stats
+    states = np.zeros((9, 2, 3, 3), np.float32)
+    states[1, 0, 1, 1] = 1
+    visits = np.zeros((9, 9), np.int32)
+    visits[0] = [11, 11, 11, 11, 11, 11, 11, 11, 11]
+    visits[1] = [0, 30, 40, 0, 0, 57, 0, 0, 0]
+    rec = GameRecord(states, visits, np.array([4, 5, -1, -1, -1, -1, -1, -1, -1]), 2, -1)
+    assert len(rec.state_history) == 2 and rec.get_state_from_history(1).shape == (1, 2, 3, 3)
+    assert rec.get_state_from_history(1).dtype == torch.float32
+    v, pol = rec.make_target(1)
+    assert v == -1 and pol == [0, 30 / 127, 40 / 127, 0, 0, 57 / 127, 0, 0, 0]
+    assert torch.cat([rec.get_state_from_history(i) for i in range(2)], 0).shape == (2, 2, 3, 3)
+    r = {"lengths": np.array([2]), "tree_size": np.array([[99, 127] + [0] * 7]),
+         "n_children": np.array([[9, 8] + [0] * 7]), "bias": np.array([[1.17, 1.18] + [0.0] * 7])}
+    st = game_stats(r, 0)
+    assert st == {"number_of_moves": 2, "average_children": 8.5, "average_tree_size": 113.0, "final_tree_size": 127,
+                  "average_bias_value": (1.17 + 1.18) / 2, "final_bias_value": 1.18}
