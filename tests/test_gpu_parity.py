@@ -274,3 +274,42 @@ def test_network_manager_inference(net_kat):
     assert tuple(p.shape) == (len(codes), 1, 3, 3) and tuple(v.shape) == (len(codes), 1)
     np.testing.assert_allclose(p.cpu().numpy().reshape(-1, 9), net_kat["C_i16_logits"], atol=2e-6)
     np.testing.assert_allclose(v.cpu().numpy().reshape(-1), net_kat["C_i16_value"], atol=1e-5)
+
+
+def test_full_size_round_equals_c_oracle():
+    """BASELINE configs[1] at full size: 4096 concurrent games, 100 simulations/move, network
+    fused into the search (persistent kernel, 8192-game round).  The C oracle replays every game
+    from the GPU network's own outputs; all visit counts, priors, actions and outcomes must be
+    identical, plus size-independent invariants of the search."""
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import cref
+    cfg = legacy_ttt_search_config(100)
+    n_games, n_slots, base = 8192, 4096, 31337
+    eng = _engine(cfg, n_games, n_slots=n_slots)
+    eng.set_weights(synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True))
+    table = _gpu_table(eng)
+    eng.play(base_seed=base)
+    r = eng.export(trace=True)
+    c = eng.counters()
+    assert eng.desync_count() == 0 and eng.live_games() == 0
+    o = cref.play_games(table, cfg, [base + g for g in range(n_games)])
+    for k in ("lengths", "outcomes", "actions", "visits", "tree_size", "n_children"):
+        assert np.array_equal(r[k], o[k]), k
+    for k in ("bias", "child_prior", "child_value_sum", "root_value_sum"):
+        assert np.array_equal(r[k], o[k]), k
+    assert c["simulations"] == o["simulations"] == int(r["lengths"].sum()) * 100
+    assert c["expansions"] == o["expansions"]
+    # invariants: a move's root children hold all but one of the root's visits; kept subtrees add up
+    L = r["lengths"]
+    for m in range(9):
+        live = L > m
+        vs = r["visits"][live, m].sum(1)
+        assert np.array_equal(vs, r["tree_size"][live, m] - 1)
+    assert (r["tree_size"][:, 0] == 100).all()
+    states = r["states"]
+    assert ((states == 0) | (states == 1)).all() and (states[:, 0] == 0).all()
+    stones = states.reshape(n_games, 9, -1).sum(2)
+    for m in range(9):
+        assert (stones[L > m, m] == m).all()
+    eng.close()

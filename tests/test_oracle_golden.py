@@ -163,3 +163,21 @@ def test_network_route_equals_reference(search_kat):
         stats, _ = osearch.play_game(game, ev, case["config"], np.random.RandomState(ref["seed"]),
                                      trace=trace)
         _check_game(ref, game, trace, stats)
+
+
+def test_c_oracle_against_reference(search_kat, net_kat):
+    """oracle/c/mcts_ref.c (used for full-size GPU checks) against the reference's golden games."""
+    from oracle import cref
+    for name, case in search_kat.items():
+        games = case["games"]
+        r = cref.play_games(full_table(net_kat, case["table"]), case["config"], [g["seed"] for g in games],
+                            training=case["training"])
+        for g, ref in enumerate(games):
+            assert r["lengths"][g] == ref["length"] and r["outcomes"][g] == ref["terminal_value"]
+            for m, mv in enumerate(ref["moves"]):
+                assert r["actions"][g, m] == mv["action"]
+                assert r["tree_size"][g, m] == mv["root_visits"] and r["bias"][g, m] == mv["bias"]
+                assert r["root_value_sum"][g, m] == mv["root_value_sum"]
+                assert r["visits"][g, m][mv["child_actions"]].tolist() == mv["child_visits"]
+                assert r["child_prior"][g, m][mv["child_actions"]].tolist() == mv["child_priors"]
+                assert r["child_value_sum"][g, m][mv["child_actions"]].tolist() == mv["child_value_sums"]
