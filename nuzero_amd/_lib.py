@@ -15,7 +15,7 @@ import torch  # noqa: F401
 from ctypes import POINTER, Structure, c_char_p, c_double, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libnuzero_amd.so")
+LIB_PATH = os.environ.get("NZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libnuzero_amd.so")   # env: timing-only ablation builds
 
 NZ_OK, NZ_ERR_ARG, NZ_ERR_HIP, NZ_ERR_STATE, NZ_ERR_OVERFLOW = range(5)
 NZ_GAME_TIC_TAC_TOE = 0

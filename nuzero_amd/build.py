@@ -15,6 +15,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libnuzero_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+COMMON += os.environ.get("NZ_EXTRA_CXXFLAGS", "").split()   # timing-only ablation builds
 UNITS = [
     ("tree.hip", ["-ffp-contract=off"]),
     ("net.hip", ["-ffp-contract=off"]),

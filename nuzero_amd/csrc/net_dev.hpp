@@ -113,7 +113,11 @@ __device__ __forceinline__ void mfma_group(f32x4 (&acc)[CELLS], const Frag& f) {
 
 template <int OMASK, int I>
 __device__ __forceinline__ void load_a1(Frag& f, const float* __restrict__ src, int a0) {
+#ifdef NZ_ABLATE_A   // timing-only build: no LDS reads of the A operands (outputs are wrong)
+  if constexpr (input_used<OMASK, I>()) { const float v = (float)(a0 + I); f.a[I] = f32x4{v, v + 1.f, v + 2.f, v + 3.f}; asm volatile("" :: "v"(src)); }
+#else
   if constexpr (input_used<OMASK, I>()) f.a[I] = *reinterpret_cast<const f32x4*>(src + a0 + I * (POS * ROW));
+#endif
 }
 // this lane's activation operands of K group kg (address of cell 0; cell I is I*1024 floats further)
 template <int OMASK>
@@ -124,9 +128,16 @@ __device__ __forceinline__ void load_a(Frag& f, const float* __restrict__ src, i
   load_a1<OMASK, 6>(f, src, a0); load_a1<OMASK, 7>(f, src, a0); load_a1<OMASK, 8>(f, src, a0);
 }
 __device__ __forceinline__ void load_b(Frag& f, const float* __restrict__ w, int lane) {
+#ifdef NZ_ABLATE_B   // timing-only build: no global loads of the B operands (outputs are wrong)
+  const float v = (float)lane * 1e-3f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) f.b[t] = f32x4{v, v + (float)t, v, v};
+  asm volatile("" :: "v"(w));
+#else
   const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(w) + lane;
 #pragma unroll
   for (int t = 0; t < 9; ++t) f.b[t] = p[t * 64];
+#endif
 }
 
 // All K groups of one job.  On entry f0.b holds the weights of the job's first K group; on

@@ -313,3 +313,65 @@ def test_full_size_round_equals_c_oracle():
     for m in range(9):
         assert (stones[L > m, m] == m).all()
     eng.close()
+
+
+@pytest.mark.parametrize("width,iters,vact,sims,n_games,n_slots", [
+    (16, 16, "tanh", 30, 40, 24),      # small net, 16 recurrent iterations, ragged tile
+    (64, 1, "relu", 400, 20, 20),      # relu value head, 400 simulations (BASELINE configs[2] search depth)
+    (32, 3, "tanh", 64, 1, 1),         # a single game
+])
+def test_fused_search_other_shapes(width, iters, vact, sims, n_games, n_slots):
+    """Other network shapes / search depths through the persistent kernel, against the C oracle
+    fed with the GPU network's outputs; network vs the torch fp32 oracle within 1e-5."""
+    from scipy.special import softmax
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import cref
+    from oracle.net import RecurrentNetRef
+    cfg = legacy_ttt_search_config(sims)
+    w = synthetic_recurrent_net_weights(11, 2, 1, width, 2, True, 1.5)
+    eng = _engine(cfg, n_games, n_slots=n_slots)
+    eng.set_weights(w, width=width, recurrent_iterations=iters, value_activation=vact)
+    table = _gpu_table(eng)
+    ref = RecurrentNetRef(w, 2, 1, width, 2, value_activation=vact)
+    codes = np.arange(0, 3 ** 9, 37)
+    p_ref, v_ref = ref.inference(_images(codes), iters)
+    np.testing.assert_allclose(table[codes, :9], softmax(p_ref.reshape(-1, 9), axis=1), atol=1e-5)
+    np.testing.assert_allclose(table[codes, 9], v_ref.reshape(-1), atol=1e-5)
+    eng.play(base_seed=5)
+    r = eng.export(trace=True)
+    o = cref.play_games(table, cfg, [5 + g for g in range(n_games)])
+    for k in ("lengths", "outcomes", "actions", "visits", "tree_size", "child_prior", "child_value_sum"):
+        assert np.array_equal(r[k], o[k]), k
+    eng.close()
+
+
+def test_error_paths():
+    """Bad arguments and out-of-order calls come back as status codes with a message."""
+    from nuzero_amd import _lib
+    from nuzero_amd._lib import NzError
+    from nuzero_amd.engine import SelfPlayEngine
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    cfg = legacy_ttt_search_config(10)
+    bad = legacy_ttt_search_config(10)
+    bad["Simulation"]["keep_subtree"] = False
+    with pytest.raises(NzError, match="keep_subtree"):
+        SelfPlayEngine(bad, 4)
+    eng = SelfPlayEngine(cfg, 4)
+    with pytest.raises(NzError) as ei:
+        eng.play(0)                      # no network yet
+    assert ei.value.code == _lib.NZ_ERR_STATE
+    w = synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True)
+    with pytest.raises(NzError):
+        eng.set_weights(dict(list(w.items())[:5]))        # wrong tensor count
+    with pytest.raises(NzError):
+        eng.set_weights(w, width=128)                     # unsupported width
+    eng.set_weights(w)
+    eng.play(0)
+    eng2 = SelfPlayEngine(cfg, 32, n_slots=16)
+    eng2.set_weights(w)
+    with pytest.raises(NzError, match="n_slots == n_games"):
+        eng2.play_lockstep(0)
+    eng.close()
+    eng2.close()
