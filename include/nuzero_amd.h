@@ -142,6 +142,19 @@ nz_status nz_engine_root_children(nz_engine* e, int32_t* n_children_dev, void* s
 nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev,
                          void* stream);
 
+/* The two halves of nz_engine_move, for evaluation matches (Testing/Tester.py:46-121 with
+ * Testing/Agents/Generic/MctsAgent.py:28-39):
+ *   nz_engine_search  root noise (training only) + the simulations, no action yet;
+ *   nz_engine_apply   select the action -- the search's own choice when actions_dev is NULL
+ *                     (MctsAgent.choose_action), else actions_dev[g] (the opponent's move in
+ *                     MctsAgent.update_subtree) -- then step, record and re-root;
+ *   nz_engine_last_actions  the action each game took at its latest move (dev int32[G], -1 if none).
+ * An agent that keeps its subtree searches on the opponent's turn too, so a match between two
+ * MCTS agents is two engines that both search every ply and both apply the mover's action. */
+nz_status nz_engine_search(nz_engine* e, const double* noise_dev, void* stream);
+nz_status nz_engine_apply(nz_engine* e, const int32_t* actions_dev, const double* uniforms_dev, void* stream);
+nz_status nz_engine_last_actions(nz_engine* e, int32_t* actions_dev, void* stream);
+
 /* 1 for every game that is not yet terminal, else 0.  dev int32[G]. */
 nz_status nz_engine_alive(nz_engine* e, int32_t* alive_dev, void* stream);
 

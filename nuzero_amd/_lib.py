@@ -59,6 +59,9 @@ SIGNATURES = {
     "nz_engine_set_table": (c_int32, [c_void_p, c_void_p, c_int32]),
     "nz_engine_reset": (c_int32, [c_void_p, c_void_p]),
     "nz_engine_root_children": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_engine_search": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_engine_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_engine_last_actions": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_engine_alive": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_engine_move": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_engine_live_games": (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),

@@ -88,7 +88,8 @@ struct TreeParams {
 void launch_reset(const TreeParams& p, hipStream_t s);
 void launch_noise(const TreeParams& p, const double* noise, hipStream_t s);
 void launch_advance(const TreeParams& p, int iteration, hipStream_t s);
-void launch_finish_move(const TreeParams& p, const double* uniforms, hipStream_t s);
+void launch_finish_move(const TreeParams& p, const double* uniforms, const int32_t* forced, hipStream_t s);
+void launch_last_actions(const TreeParams& p, int32_t* actions, hipStream_t s);
 void launch_export_states(const TreeParams& p, float* states, hipStream_t s);
 void launch_export_visits(const TreeParams& p, int32_t* visits, int32_t* actions, int32_t* tree_size,
                           int32_t* n_children, double* bias, hipStream_t s);

@@ -224,7 +224,7 @@ nz_status check_device_flag(nz_engine* e, hipStream_t s) {
   NZ_HIP(e, hipStreamSynchronize(s));
   if (flag != 0)
     return fail(e, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 = tree arena full, 2 = visit table too short, "
-                                    "4 = move finished before its search)", flag);
+                                    "4 = move finished before its search, 8 = forced action is not legal)", flag);
   return NZ_OK;
 }
 
@@ -508,15 +508,8 @@ nz_status nz_engine_alive(nz_engine* e, int32_t* alive_dev, void* stream) {
   return NZ_OK;
 }
 
-nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev, void* stream) {
-  if (!e) return NZ_ERR_ARG;
-  if (e->n_slots != e->n_games)
-    return fail(e, NZ_ERR_STATE, "the lock-step route needs n_slots == n_games (every game of the round in flight)");
-  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
-  if (e->cfg.training && (!noise_dev || !uniforms_dev))
-    return fail(e, NZ_ERR_ARG, "training search needs noise and uniforms");
-  NZ_HIP(e, hipSetDevice(e->device));
-  hipStream_t s = as_stream(stream);
+// noise + simulations of one move for every live game (no action yet)
+static nz_status search_lockstep(nz_engine* e, const double* noise_dev, hipStream_t s) {
   const TreeParams& p = e->tp;
   if (e->cfg.training) {
     Span sp(e, s, 2);
@@ -541,10 +534,63 @@ nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* un
       }
     }
   }
+  return NZ_OK;
+}
+
+static nz_status check_lockstep_call(nz_engine* e, const double* noise_dev, const double* uniforms_dev, bool need_uni) {
+  if (e->n_slots != e->n_games)
+    return fail(e, NZ_ERR_STATE, "the lock-step route needs n_slots == n_games (every game of the round in flight)");
+  if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
+  if (e->cfg.training && (!noise_dev || (need_uni && !uniforms_dev)))
+    return fail(e, NZ_ERR_ARG, "training search needs noise and uniforms");
+  return NZ_OK;
+}
+
+nz_status nz_engine_move(nz_engine* e, const double* noise_dev, const double* uniforms_dev, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  nz_status st = check_lockstep_call(e, noise_dev, uniforms_dev, true);
+  if (st != NZ_OK) return st;
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  search_lockstep(e, noise_dev, s);
   {
     Span sp(e, s, 2);
-    launch_finish_move(p, uniforms_dev, s);
+    launch_finish_move(e->tp, uniforms_dev, nullptr, s);
   }
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_search(nz_engine* e, const double* noise_dev, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  nz_status st = check_lockstep_call(e, noise_dev, nullptr, false);
+  if (st != NZ_OK) return st;
+  NZ_HIP(e, hipSetDevice(e->device));
+  search_lockstep(e, noise_dev, as_stream(stream));
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_apply(nz_engine* e, const int32_t* actions_dev, const double* uniforms_dev, void* stream) {
+  if (!e) return NZ_ERR_ARG;
+  if (e->n_slots != e->n_games)
+    return fail(e, NZ_ERR_STATE, "the lock-step route needs n_slots == n_games (every game of the round in flight)");
+  if (!actions_dev && e->cfg.training && !uniforms_dev)
+    return fail(e, NZ_ERR_ARG, "a training engine choosing its own action needs uniforms");
+  NZ_HIP(e, hipSetDevice(e->device));
+  hipStream_t s = as_stream(stream);
+  {
+    Span sp(e, s, 2);
+    launch_finish_move(e->tp, uniforms_dev, actions_dev, s);
+  }
+  NZ_HIP(e, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_engine_last_actions(nz_engine* e, int32_t* actions_dev, void* stream) {
+  if (!e || !actions_dev) return NZ_ERR_ARG;
+  NZ_HIP(e, hipSetDevice(e->device));
+  launch_last_actions(e->tp, actions_dev, as_stream(stream));
   NZ_HIP(e, hipGetLastError());
   return NZ_OK;
 }

@@ -154,7 +154,8 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
   }
 }
 
-__global__ void finish_move_kernel(TreeParams p, const double* __restrict__ uniforms) {
+__global__ void finish_move_kernel(TreeParams p, const double* __restrict__ uniforms,
+                                   const int32_t* __restrict__ forced) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= p.n_games) return;
   if (!p.alive[g]) {
@@ -167,7 +168,7 @@ __global__ void finish_move_kernel(TreeParams p, const double* __restrict__ unif
   }
   const int move = p.length[g];
   const MoveResult r = finish_move_one(p, arena_of(p, g), g, p.root[g], p.board[g], move,
-                                       uniforms ? uniforms + (size_t)g * 3 : nullptr);
+                                       uniforms ? uniforms + (size_t)g * 3 : nullptr, forced ? forced[g] : -1);
   if (r.chosen < 0) return;
   p.board[g] = r.new_board;
   p.length[g] = move + 1;
@@ -181,6 +182,14 @@ __global__ void finish_move_kernel(TreeParams p, const double* __restrict__ unif
   } else {
     p.n_root_children[g] = r.new_children;
   }
+}
+
+// action taken at each game's most recent move, -1 before the first
+__global__ void last_actions_kernel(TreeParams p, int32_t* __restrict__ actions) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  const int n = p.length[g];
+  actions[g] = n > 0 ? p.hist_action[g * TTT_MAX_MOVES + n - 1] : -1;
 }
 
 __global__ void export_states_kernel(TreeParams p, float* __restrict__ states) {
@@ -220,8 +229,11 @@ void launch_advance(const TreeParams& p, int iteration, hipStream_t s) {
   const int blocks = (p.n_games + GAMES_PER_BLOCK - 1) / GAMES_PER_BLOCK;
   hipLaunchKernelGGL(advance_kernel, dim3(blocks), dim3(BLOCK), 0, s, p, iteration);
 }
-void launch_finish_move(const TreeParams& p, const double* uniforms, hipStream_t s) {
-  hipLaunchKernelGGL(finish_move_kernel, dim3((p.n_games + 255) / 256), dim3(256), 0, s, p, uniforms);
+void launch_finish_move(const TreeParams& p, const double* uniforms, const int32_t* forced, hipStream_t s) {
+  hipLaunchKernelGGL(finish_move_kernel, dim3((p.n_games + 255) / 256), dim3(256), 0, s, p, uniforms, forced);
+}
+void launch_last_actions(const TreeParams& p, int32_t* actions, hipStream_t s) {
+  hipLaunchKernelGGL(last_actions_kernel, dim3((p.n_games + 255) / 256), dim3(256), 0, s, p, actions);
 }
 void launch_export_states(const TreeParams& p, float* states, hipStream_t s) {
   const int total = p.n_games * TTT_MAX_MOVES * 18;

@@ -429,8 +429,10 @@ struct MoveResult {
 // Explorer.select_action (Explorer.py:70-97), the per-move records Gamer keeps
 // (Gamer.py:71-77,81-92), game.step (tic_tac_toe.py:161-167) and re-rooting
 // (Gamer.py:78-79).  `record` is the game's row in the hist_* arrays.
+// `forced` >= 0 plays that action instead of the search's own choice (the opponent's move in
+// MctsAgent.update_subtree, Testing/Agents/Generic/MctsAgent.py:35-39).
 __device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t, int record, int root,
-                                             uint32_t board, int move, const double* uni3) {
+                                             uint32_t board, int move, const double* uni3, int forced = -1) {
   MoveResult r{-1, root, board, 0, 0};
   const uint2 lk = t.link[root];
   const int k = (int)meta_children(lk.y);
@@ -456,9 +458,11 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t
   p.hist_bias[gm] = root_visits < p.tab_len ? p.bias_tab[root_visits] : 0.0;
   p.hist_root_value_sum[gm] = t.value_sum[root];
 
-  int mode = 0;       // 0 max, 1 softmax over visit counts, 2 uniform over legal
+  int mode = 0;       // 0 max, 1 softmax over visit counts, 2 uniform over legal, 3 forced
   double u3 = 0.0;
-  if (p.training) {
+  if (forced >= 0) {
+    mode = 3;
+  } else if (p.training) {
     const double u1 = uni3[0], u2 = uni3[1];
     u3 = uni3[2];
     if (move < p.softmax_moves) mode = 1;
@@ -481,6 +485,14 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t
     const double s2 = np_sum(e, k);
     for (int j = 0; j < k; ++j) e[j] = e[j] / s2;
     chosen = actions[np_choice(e, k, u3)];
+  } else if (mode == 3) {
+    chosen = -1;
+    for (int j = 0; j < k; ++j)
+      if (actions[j] == forced) chosen = forced;
+    if (chosen < 0) {           // not a legal move of this position
+      atomicOr(p.error_flag, 8);
+      return r;
+    }
   } else {                    // uniform over legal actions (Explorer.py:86-89)
     const uint32_t empty = ttt_empty(board);
     double m[TTT_ACTIONS];

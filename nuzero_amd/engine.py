@@ -129,6 +129,28 @@ class SelfPlayEngine:
         with torch.cuda.device(self.device):
             check(lib.nz_engine_move(self._h, _ptr(noise), _ptr(uniforms), _stream()), self._h)
 
+    def search(self, noise=None):
+        """Root noise (training) + simulations for every live game; no action yet."""
+        if noise is not None:
+            noise = torch.as_tensor(noise, dtype=torch.float64).to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_search(self._h, _ptr(noise), _stream()), self._h)
+
+    def apply(self, actions=None, uniforms=None):
+        """Take `actions` (int32 [G]; None = the search's own choice), step and re-root."""
+        if actions is not None:
+            actions = torch.as_tensor(actions, dtype=torch.int32).to(self.device).contiguous()
+        if uniforms is not None:
+            uniforms = torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_apply(self._h, _ptr(actions), _ptr(uniforms), _stream()), self._h)
+
+    def last_actions(self):
+        out = torch.empty((self.n_games,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            check(lib.nz_engine_last_actions(self._h, _ptr(out), _stream()), self._h)
+        return out
+
     def live_games(self):
         n = c_int32(0)
         with torch.cuda.device(self.device):

@@ -375,3 +375,40 @@ def test_error_paths():
         eng2.play_lockstep(0)
     eng.close()
     eng2.close()
+
+
+@pytest.mark.parametrize("sims1,tab1,sims2,tab2", [(20, "A", 50, "B"), (60, "B", 15, "A"), (33, "C", 33, "C")])
+def test_evaluation_match_between_two_mcts_agents(net_kat, sims1, tab1, sims2, tab2):
+    """Tester.Test_using_agents with two MctsAgents that keep their subtrees: two engines
+    (training=False), both search every ply, both apply the mover's action."""
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import ttt as ottt, search as osearch
+    from oracle.agents import MctsAgentRef, play_match
+    cfg1, cfg2 = legacy_ttt_search_config(sims1), legacy_ttt_search_config(sims2)
+    t1, t2 = full_table(net_kat, tab1), full_table(net_kat, tab2)
+    game = ottt.TicTacToe()
+    want = play_match(game, MctsAgentRef(cfg1, osearch.table_evaluator(t1)),
+                      MctsAgentRef(cfg2, osearch.table_evaluator(t2)))
+    e1, e2 = _engine(cfg1, 3, training=False), _engine(cfg2, 3, training=False)
+    e1.set_table(t1)
+    e2.set_table(t2)
+    e1.reset()
+    e2.reset()
+    got = []
+    ply = 0
+    while e1.live_games() > 0:
+        mover, other = (e1, e2) if ply % 2 == 0 else (e2, e1)
+        mover.search()
+        other.search()                       # update_subtree: the opponent searches the same position
+        mover.apply()                        # choose_action
+        a = mover.last_actions()
+        other.apply(actions=a)
+        got.append(int(a[0]))
+        assert (a == a[0]).all()
+        ply += 1
+    assert got == want
+    r1, r2 = e1.export(), e2.export()
+    assert r1["outcomes"][0] == r2["outcomes"][0] == game.terminal_value
+    assert np.array_equal(r1["actions"], r2["actions"])
+    e1.close()
+    e2.close()
