@@ -168,6 +168,10 @@ __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], Frag& f0, Frag& f
   }
 }
 
+// tanh for the value head: 1 - 2 / (exp(2x) + 1) on the hardware exp; absolute error < 3e-7
+// (the parity tolerance on values is 1e-5), exact limits at +-inf
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f / (__expf(2.0f * x) + 1.0f); }
+
 template <int OMASK, int TAP, int I>
 __device__ __forceinline__ void mfma_extra_pair(f32x4 (&acc)[CELLS], const float (&ax)[CELLS], const float (&bx)[9]) {
   if constexpr (pair_used<OMASK, I, TAP>()) {
@@ -223,7 +227,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], float* _
       if (!((OMASK >> o) & 1)) continue;
       float x = v[o][r];
       if constexpr (ACT == 1) x = fmaxf(x, 0.0f);
-      if constexpr (ACT == 2) x = tanhf(x);
+      if constexpr (ACT == 2) x = tanh_fast(x);
       dst[o * (POS * ROW) + off[r]] = x;
     }
 }
@@ -265,7 +269,7 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
             float s = 0.0f;
 #pragma unroll
             for (int o = 0; o < CELLS; ++o) s += acc[o][r];
-            value[gp] = tanhf(s / 9.0f);
+            value[gp] = tanh_fast(s / 9.0f);
           }
         }
       }
