@@ -161,10 +161,17 @@ def main():
         pc = eng.counters()
         k_ms, k_n = prof["search"]["ms"], prof["search"]["launches"]
         achieved = pc["expansions"] * flops_pos / (k_ms * 1e-3) / 1e12
+        # HBM bytes per launch of this kernel from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs,
+        # profiles/r01_pmc_traffic.json); only quoted for the configuration they were collected on
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and (args.games, n_round, args.sims, args.iters) == (4096, 16384, 100, 2):
+            with open(tpath) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_raw"]
         out["roofline"] = {
             "bound": "mfma", "kernel": "selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
             "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
             "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(k_n, 1),
             "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n}
         # ---- in-kernel phase shares (stamped diagnostic build; its run time is not quoted)
@@ -185,24 +192,37 @@ def main():
                                "achieved": net_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": net_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
                                "avg_launch_us": pn["ms"] * 1e3 / 20}
-        # ---- the lock-step tree kernel against HBM (SURVEY.md 8d bytes: 11 + 20 k per scored node,
-        #      24 per path node backed up)
-        ls = SelfPlayEngine(cfg, args.games, training=True, device=local_rank)
-        ls.set_weights(weights, recurrent_iterations=args.iters)
-        ls.play_lockstep(base_seed=0)
-        ls.profile(True)
-        ls.play_lockstep(base_seed=args.games)
-        pl = ls.profile_read()["search"]
-        ls.profile(False)
-        lc = ls.counters()
-        sel_bytes = 11 * lc["select_nodes"] + 20 * lc["select_children"] + 24 * (lc["select_nodes"] + lc["simulations"])
-        sel_gbs = sel_bytes / (pl["ms"] * 1e-3) / 1e9
-        out["roofline_select"] = {"bound": "hbm", "kernel": "advance_kernel (lock-step select + expand + backup)",
-                                  "achieved": sel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": sel_gbs / HBM_PEAK_GBS, "traffic": None,
-                                  "bytes_per_launch": sel_bytes / max(pl["launches"], 1),
-                                  "avg_launch_us": pl["ms"] * 1e3 / max(pl["launches"], 1), "launches": pl["launches"]}
-        ls.close()
+        # ---- the tree kernel alone against HBM (SURVEY.md 8d bytes: 11 + 20 k per scored node, 24 per
+        #      path node backed up): lock-step route with a table evaluator, so advance_kernel does a whole
+        #      move's select/expand/backup per launch; at the workload's 4096 trees and at 65536 trees
+        rs = np.random.RandomState(0)
+        table = np.zeros((3 ** 9, 10), np.float32)
+        table[:, :9] = rs.dirichlet(np.ones(9), 3 ** 9)
+        table[:, 9] = rs.uniform(-0.5, 0.5, 3 ** 9)
+        sel = {}
+        for n_trees in (args.games, 65536):
+            ls = SelfPlayEngine(cfg, n_trees, training=True, device=local_rank)
+            ls.set_table(table)
+            ls.play_lockstep(base_seed=0)
+            ls.profile(True)
+            ls.play_lockstep(base_seed=n_trees)
+            pl = ls.profile_read()["search"]
+            ls.profile(False)
+            lc = ls.counters()
+            sel_bytes = (11 * lc["select_nodes"] + 20 * lc["select_children"]
+                         + 24 * (lc["select_nodes"] + lc["simulations"]))
+            sel[n_trees] = {"achieved": sel_bytes / (pl["ms"] * 1e-3) / 1e9,
+                            "bytes_per_launch": sel_bytes / max(pl["launches"], 1),
+                            "avg_launch_us": pl["ms"] * 1e3 / max(pl["launches"], 1), "launches": pl["launches"],
+                            "simulations_per_s": lc["simulations"] / (pl["ms"] * 1e-3)}
+            ls.close()
+        big = sel[65536]
+        out["roofline_select"] = {"bound": "hbm", "kernel": "advance_kernel (select + expand + backup, table evaluator, "
+                                  "65536 concurrent trees)", "achieved": big["achieved"], "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": big["achieved"] / HBM_PEAK_GBS, "traffic": None,
+                                  "bytes_per_launch": big["bytes_per_launch"], "avg_launch_us": big["avg_launch_us"],
+                                  "launches": big["launches"], "simulations_per_s": big["simulations_per_s"],
+                                  "at_workload_trees": dict(sel[args.games], trees=args.games)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
