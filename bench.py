@@ -174,6 +174,7 @@ def main():
             "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
             "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(k_n, 1),
             "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n}
+    if not args.no_extras and world == 1:
         # ---- in-kernel phase shares (stamped diagnostic build; its run time is not quoted)
         eng.phase_stamps(True)
         eng.play(base_seed=2 * 10 ** 6 + rank * n_round)
