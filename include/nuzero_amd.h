@@ -39,6 +39,7 @@ enum {
 
 enum { NZ_GAME_TIC_TAC_TOE = 0 };
 enum { NZ_ACT_TANH = 0, NZ_ACT_RELU = 1 };
+enum { NZ_ARCH_RECURRENT = 0, NZ_ARCH_RESNET = 1, NZ_ARCH_CONVNET = 2 };
 
 /* Search hyper-parameters: exactly the keys the reference's Explorer reads
  * from its search config (Configs/Search/Examples/documentation_search_config.yaml:1-47;
@@ -64,16 +65,24 @@ typedef struct nz_game_desc {
   int32_t negate_player;                /* Q is negated iff parent.to_play == this (Explorer.py:124) */
 } nz_game_desc;
 
-/* RecurrentNet(in_channels, policy_channels, num_filters, num_blocks, recall,
- * policy_head="conv", value_head="reduce", value_activation, hex=False)
- * (Neural_Networks/Architectures/RecurrentNet.py:18-79). */
+/* The square-conv (hex=False) policy/value networks of the reference, all with the
+ * "conv" policy head and the "reduce" value head (blocks.py:46-92,130-170):
+ *   NZ_ARCH_RECURRENT  RecurrentNet(in_channels, policy_channels, num_filters=width, num_blocks,
+ *                      recall, value_activation)   (Architectures/RecurrentNet.py:18-99)
+ *   NZ_ARCH_RESNET     ResNet(in_channels, policy_channels, num_filters=width, num_blocks,
+ *                      batch_norm=False, value_activation)     (Architectures/ResNet.py:13-70)
+ *   NZ_ARCH_CONVNET    ConvNet(in_channels, policy_channels, kernel_size, num_filters=width,
+ *                      num_layers=num_blocks)  -- ELU trunk          (Architectures/ConvNet.py:12-57)
+ * Weights are passed in the model's state_dict order. */
 typedef struct nz_net_desc {
   int32_t in_channels;
   int32_t policy_channels;
   int32_t width;
-  int32_t num_blocks;
-  int32_t recall;
+  int32_t num_blocks;                   /* residual blocks; ConvNet: num_layers */
+  int32_t recall;                       /* RecurrentNet only */
   int32_t value_activation;             /* NZ_ACT_* */
+  int32_t arch;                         /* NZ_ARCH_* */
+  int32_t kernel_size;                  /* ConvNet trunk: 1 or 3; others: 3 */
 } nz_net_desc;
 
 /* Fixed per-engine sizes, for sizing the caller's export buffers. */

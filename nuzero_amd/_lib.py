@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("NZ_LIB_PATH") or os.path.join(_HERE, "csrc", "libnuze
 NZ_OK, NZ_ERR_ARG, NZ_ERR_HIP, NZ_ERR_STATE, NZ_ERR_OVERFLOW = range(5)
 NZ_GAME_TIC_TAC_TOE = 0
 NZ_ACT_TANH, NZ_ACT_RELU = 0, 1
+NZ_ARCH_RECURRENT, NZ_ARCH_RESNET, NZ_ARCH_CONVNET = 0, 1, 2
 
 
 class SearchCfg(Structure):
@@ -37,7 +38,8 @@ class GameDesc(Structure):
 
 class NetDesc(Structure):
     _fields_ = [("in_channels", c_int32), ("policy_channels", c_int32), ("width", c_int32),
-                ("num_blocks", c_int32), ("recall", c_int32), ("value_activation", c_int32)]
+                ("num_blocks", c_int32), ("recall", c_int32), ("value_activation", c_int32),
+                ("arch", c_int32), ("kernel_size", c_int32)]
 
 
 class Dims(Structure):

@@ -392,62 +392,82 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   if (net->width <= 0 || net->width > 64 || net->width % 4 != 0)
     return fail(e, NZ_ERR_ARG, "width must be a multiple of 4 in (0, 64]");
   if (net->num_blocks < 0 || recurrent_iterations < 0) return fail(e, NZ_ERR_ARG, "negative block/iteration count");
-  const int expect = 1 + (net->recall ? 1 : 0) + 2 * net->num_blocks + 2 + 4;
+  const int arch = net->arch;
+  if (arch != NZ_ARCH_RECURRENT && arch != NZ_ARCH_RESNET && arch != NZ_ARCH_CONVNET)
+    return fail(e, NZ_ERR_ARG, "unknown architecture %d", arch);
+  const int trunk_k = arch == NZ_ARCH_CONVNET ? net->kernel_size : 3;
+  if (trunk_k != 1 && trunk_k != 3) return fail(e, NZ_ERR_ARG, "ConvNet kernel_size must be 1 or 3");
+  const bool recall = arch == NZ_ARCH_RECURRENT && net->recall;
+  const int iterations = arch == NZ_ARCH_RECURRENT ? recurrent_iterations : 1;
+  const int trunk_tensors = arch == NZ_ARCH_CONVNET ? 1 + net->num_blocks : 1 + (recall ? 1 : 0) + 2 * net->num_blocks;
+  const int expect = trunk_tensors + 2 + 4;
   if (n_tensors != expect) return fail(e, NZ_ERR_ARG, "expected %d weight tensors, got %d", expect, n_tensors);
-  const int per_iter = (net->recall ? 1 : 0) + 2 * net->num_blocks;
-  if (1 + recurrent_iterations * per_iter + 24 > NET_MAX_JOBS)
+  if (1 + iterations * (trunk_tensors - 1) + 24 > NET_MAX_JOBS)
     return fail(e, NZ_ERR_ARG, "too many layers for one fused launch (%d iterations)", recurrent_iterations);
   NZ_HIP(e, hipSetDevice(e->device));
 
   const int W = net->width, IN = net->in_channels;
-  // tensor shapes in state_dict order (RecurrentNet.py:18-79)
-  struct Shape { int cout, cin; };
+  // tensor shapes in state_dict order
+  struct Shape { int cout, cin, k; };
   std::vector<Shape> shapes;
-  shapes.push_back({W, IN});
-  if (net->recall) shapes.push_back({W, W + IN});
-  for (int b = 0; b < 2 * net->num_blocks; ++b) shapes.push_back({W, W});
+  shapes.push_back({W, IN, trunk_k});
+  if (recall) shapes.push_back({W, W + IN, 3});
+  for (int i = (int)shapes.size(); i < trunk_tensors; ++i) shapes.push_back({W, W, trunk_k});
   for (int i = 0; i < 2; ++i)
-    shapes.push_back({head_channel(W, net->policy_channels, 2, i + 1), head_channel(W, net->policy_channels, 2, i)});
-  for (int i = 0; i < 4; ++i) shapes.push_back({head_channel(W, 1, 4, i + 1), head_channel(W, 1, 4, i)});
+    shapes.push_back({head_channel(W, net->policy_channels, 2, i + 1), head_channel(W, net->policy_channels, 2, i), 3});
+  for (int i = 0; i < 4; ++i) shapes.push_back({head_channel(W, 1, 4, i + 1), head_channel(W, 1, 4, i), 3});
 
   std::vector<std::vector<float>> host(n_tensors);
   for (int i = 0; i < n_tensors; ++i) {
-    host[i].resize((size_t)shapes[i].cout * shapes[i].cin * 9);
-    NZ_HIP(e, hipMemcpy(host[i].data(), weights[i], host[i].size() * sizeof(float), hipMemcpyDefault));
+    const size_t n_in = (size_t)shapes[i].cout * shapes[i].cin * shapes[i].k * shapes[i].k;
+    std::vector<float> raw(n_in);
+    NZ_HIP(e, hipMemcpy(raw.data(), weights[i], n_in * sizeof(float), hipMemcpyDefault));
+    if (shapes[i].k == 3) {
+      host[i].swap(raw);
+    } else {                                   // 1x1 conv = a 3x3 conv whose only tap is the centre
+      host[i].assign((size_t)shapes[i].cout * shapes[i].cin * 9, 0.f);
+      for (size_t j = 0; j < n_in; ++j) host[i][j * 9 + 4] = raw[j];
+    }
   }
 
   std::vector<float> packed;
   std::vector<PackedConv> convs(n_tensors);
-  double flops = 0.0;   // in-bounds taps only: 2 * Cout * Cin * 49 per conv application
+  double flops = 0.0;   // in-bounds taps only: 2 * Cout * Cin * 49 per 3x3 conv application (9 for 1x1)
   for (int i = 0; i < n_tensors; ++i) {
-    const bool with_planes = (i == 0) || (net->recall && i == 1);
+    const bool with_planes = (i == 0) || (recall && i == 1);
     const int cin_main = with_planes ? shapes[i].cin - IN : shapes[i].cin;
     convs[i] = pack_conv(host[i].data(), shapes[i].cout, shapes[i].cin, cin_main, packed);
   }
 
-  // stages; activation buffers 0/1 ping-pong, `cur` holds the running thought, 2 is the
-  // value head's side buffer; dst 3 = policy logits, 4 = value
+  // stages; activation buffers 0/1 ping-pong, `cur` holds the running trunk output, 2 is the
+  // value head's side buffer; dst 3 = policy logits, 4 = value.  act: 1 relu, 2 tanh, 3 elu
   NetProgram& pg = e->prog_host;
   memset(&pg, 0, sizeof(pg));
   bool ok = true;
   int cur = 0;
   auto stage = [&](std::vector<StageConv> convs_in_stage) {
-    for (const StageConv& sc : convs_in_stage) flops += 2.0 * shapes[sc.tensor].cout * shapes[sc.tensor].cin * 49.0;
+    for (const StageConv& sc : convs_in_stage)
+      flops += 2.0 * shapes[sc.tensor].cout * shapes[sc.tensor].cin * (shapes[sc.tensor].k == 3 ? 49.0 : 9.0);
     ok = ok && add_stage(pg, convs, convs_in_stage);
   };
-  stage({{0, 0, cur, -1, 1, false}});                                   // projection + ReLU
-  const int first_block = net->recall ? 2 : 1;
-  for (int it = 0; it < recurrent_iterations; ++it) {
-    if (net->recall) { stage({{1, cur, cur ^ 1, -1, 0, false}}); cur ^= 1; }   // cat([thought, x]) conv, no activation
-    for (int b = 0; b < net->num_blocks; ++b) {                                    // relu(conv2(relu(conv1(t))) + t)
-      stage({{first_block + 2 * b, cur, cur ^ 1, -1, 1, false}});
-      stage({{first_block + 2 * b + 1, cur ^ 1, cur, cur, 1, false}});
+  if (arch == NZ_ARCH_CONVNET) {                                      // ConvNet.py:20-40: (conv, ELU) x (1 + num_layers)
+    stage({{0, 0, cur, -1, 3, false}});
+    for (int i = 1; i < trunk_tensors; ++i) { stage({{i, cur, cur ^ 1, -1, 3, false}}); cur ^= 1; }
+  } else {
+    stage({{0, 0, cur, -1, 1, false}});                               // projection / input block + ReLU
+    const int first_block = recall ? 2 : 1;
+    for (int it = 0; it < iterations; ++it) {
+      if (recall) { stage({{1, cur, cur ^ 1, -1, 0, false}}); cur ^= 1; }   // cat([thought, x]) conv, no activation
+      for (int b = 0; b < net->num_blocks; ++b) {                         // relu(conv2(relu(conv1(t))) + t)
+        stage({{first_block + 2 * b, cur, cur ^ 1, -1, 1, false}});
+        stage({{first_block + 2 * b + 1, cur ^ 1, cur, cur, 1, false}});
+      }
     }
   }
-  const int ph = first_block + 2 * net->num_blocks, vh = ph + 2;
+  const int ph = trunk_tensors, vh = ph + 2;
   const int vact = net->value_activation == NZ_ACT_RELU ? 1 : 2;
   const int side = cur ^ 1;
-  stage({{ph, cur, side, -1, 1, true}, {vh, cur, 2, -1, vact, true}});      // both heads read the thought
+  stage({{ph, cur, side, -1, 1, true}, {vh, cur, 2, -1, vact, true}});      // both heads read the trunk output
   stage({{ph + 1, side, 3, -1, 0, true}, {vh + 1, 2, cur, -1, vact, true}});
   stage({{vh + 2, cur, side, -1, vact, true}});
   stage({{vh + 3, side, 4, -1, 0, false}});                                 // mean over cells needs all nine

@@ -228,6 +228,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], float* _
       float x = v[o][r];
       if constexpr (ACT == 1) x = fmaxf(x, 0.0f);
       if constexpr (ACT == 2) x = tanh_fast(x);
+      if constexpr (ACT == 3) x = x > 0.0f ? x : expm1f(x);      // nn.ELU(), alpha = 1
       dst[o * (POS * ROW) + off[r]] = x;
     }
 }
@@ -244,6 +245,8 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
       epilogue_lds<OMASK, 1, false>(acc, dst, nullptr, lane, job.nt);
     } else if (job.act == 2) {
       epilogue_lds<OMASK, 2, false>(acc, dst, nullptr, lane, job.nt);
+    } else if (job.act == 3) {
+      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 3, false>(acc, dst, nullptr, lane, job.nt);
     } else {
       epilogue_lds<OMASK, 0, false>(acc, dst, nullptr, lane, job.nt);
     }

@@ -59,9 +59,9 @@ class SelfPlayEngine:
 
     # ---- network ---------------------------------------------------------------
     def set_weights(self, weights, width=64, num_blocks=2, recall=True, value_activation="tanh",
-                    recurrent_iterations=2, in_channels=2, policy_channels=1):
-        """``weights``: name -> array/tensor with the reference's state_dict keys
-        (RecurrentNet, hex=False), in state_dict order."""
+                    recurrent_iterations=2, in_channels=2, policy_channels=1, arch="recurrent", kernel_size=3):
+        """``weights``: name -> array/tensor with the reference's state_dict keys (hex=False
+        RecurrentNet, ResNet or ConvNet; for ConvNet num_blocks = num_layers), in state_dict order."""
         tensors = []
         for v in weights.values():
             t = v.detach() if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))
@@ -69,7 +69,9 @@ class SelfPlayEngine:
         ptrs = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         nd = _lib.NetDesc(in_channels=in_channels, policy_channels=policy_channels, width=width,
                           num_blocks=num_blocks, recall=int(recall),
-                          value_activation=_lib.NZ_ACT_RELU if value_activation == "relu" else _lib.NZ_ACT_TANH)
+                          value_activation=_lib.NZ_ACT_RELU if value_activation == "relu" else _lib.NZ_ACT_TANH,
+                          arch={"recurrent": _lib.NZ_ARCH_RECURRENT, "resnet": _lib.NZ_ARCH_RESNET,
+                                "convnet": _lib.NZ_ARCH_CONVNET}[arch], kernel_size=kernel_size)
         for t in tensors:
             if t.is_cuda:
                 torch.cuda.synchronize(t.device)

@@ -120,7 +120,8 @@ class Gamer:
             s = nm.spec()
             self.engine.set_weights(nm.state_dict(), width=s.width, num_blocks=s.num_blocks, recall=s.recall,
                                     value_activation=s.value_activation,
-                                    recurrent_iterations=self.recurrent_iterations)
+                                    recurrent_iterations=self.recurrent_iterations, arch=s.arch,
+                                    kernel_size=s.kernel_size)
             self._loaded = nm
         self.engine.play(base_seed=self.base_seed)
         self.base_seed += self.num_games

@@ -17,19 +17,31 @@ class RecurrentNetSpec:
     (Neural_Networks/Architectures/RecurrentNet.py:18-79) as plain numbers."""
 
     def __init__(self, in_channels=2, policy_channels=1, width=64, num_blocks=2, recall=True,
-                 value_activation="tanh"):
+                 value_activation="tanh", arch="recurrent", kernel_size=3):
         self.in_channels, self.policy_channels = in_channels, policy_channels
         self.width, self.num_blocks, self.recall = width, num_blocks, recall
         self.value_activation = value_activation
+        self.arch, self.kernel_size = arch, kernel_size      # "recurrent" | "resnet" | "convnet"
 
     @classmethod
     def from_state_dict(cls, sd, value_activation="tanh"):
-        proj = sd["projection.0.weight"]
-        width, in_channels = int(proj.shape[0]), int(proj.shape[1])
-        recall = "recur_module.0.weight" in sd
-        n_block_convs = sum(1 for k in sd if ".before_shortcut." in k)
+        """Recognise RecurrentNet / ResNet / ConvNet (hex=False) by their parameter names."""
         policy_channels = int(sd["policy_head.layers.2.weight"].shape[0])
-        return cls(in_channels, policy_channels, width, n_block_convs // 2, recall, value_activation)
+        n_block_convs = sum(1 for k in sd if ".before_shortcut." in k)
+        if "projection.0.weight" in sd:
+            first = sd["projection.0.weight"]
+            return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_block_convs // 2,
+                       "recur_module.0.weight" in sd, value_activation, "recurrent", 3)
+        if "input_block.0.weight" in sd:
+            first = sd["input_block.0.weight"]
+            return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_block_convs // 2, False,
+                       value_activation, "resnet", 3)
+        if "general_module.0.weight" in sd:
+            first = sd["general_module.0.weight"]
+            n_layers = sum(1 for k in sd if k.startswith("general_module.")) - 1
+            return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_layers, False,
+                       value_activation, "convnet", int(first.shape[2]))
+        raise ValueError("unrecognised network: expected RecurrentNet, ResNet or ConvNet parameter names")
 
 
 class Network_Manager:
@@ -42,14 +54,12 @@ class Network_Manager:
         if isinstance(model, dict):
             self._sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
                         for k, v in model.items()}
-            self.recurrent = True
+            self.recurrent = "projection.0.weight" in self._sd
         else:
             if not hasattr(model, "recurrent") or not isinstance(model.recurrent, bool):
                 raise Exception('You need to add a "recurrent" boolean attribute to the model')
-            if not model.recurrent:
-                raise NotImplementedError("only the recurrent square-conv net runs on the fused kernel")
             self._sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-            self.recurrent = True
+            self.recurrent = model.recurrent
         self._spec = RecurrentNetSpec.from_state_dict(self._sd, value_activation)
         self._engine = None
 
@@ -81,7 +91,8 @@ class Network_Manager:
                 self._engine = SelfPlayEngine(legacy_ttt_search_config(), 16)
             s = self._spec
             self._engine.set_weights(self._sd, width=s.width, num_blocks=s.num_blocks, recall=s.recall,
-                                     value_activation=s.value_activation, recurrent_iterations=iters_to_do)
+                                     value_activation=s.value_activation, recurrent_iterations=iters_to_do,
+                                     arch=s.arch, kernel_size=s.kernel_size)
         logits, value, _ = self._engine.net_forward(state, want_probs=False)
         b = logits.shape[0]
         return logits.reshape(b, self._spec.policy_channels, 3, 3), value.reshape(b, 1)

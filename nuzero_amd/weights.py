@@ -45,6 +45,45 @@ def recurrent_net_param_shapes(in_channels, policy_channels, width=64, num_block
     return shapes
 
 
+def resnet_param_shapes(in_channels, policy_channels, width=64, num_blocks=4):
+    """ResNet(..., hex=False, batch_norm=False) (Neural_Networks/Architectures/ResNet.py:13-70)."""
+    shapes = [("input_block.0.weight", (width, in_channels, 3, 3))]
+    for b in range(num_blocks):
+        shapes.append((f"residual_blocks.{b}.before_shortcut.0.weight", (width, width, 3, 3)))
+        shapes.append((f"residual_blocks.{b}.before_shortcut.2.weight", (width, width, 3, 3)))
+    return shapes + _head_shapes(width, policy_channels)
+
+
+def convnet_param_shapes(in_channels, policy_channels, kernel_size=3, width=64, num_layers=6):
+    """ConvNet(..., hex=False) (Neural_Networks/Architectures/ConvNet.py:12-57)."""
+    k = kernel_size
+    shapes = [("general_module.0.weight", (width, in_channels, k, k))]
+    for i in range(num_layers):
+        shapes.append((f"general_module.{2 * (i + 1)}.weight", (width, width, k, k)))
+    return shapes + _head_shapes(width, policy_channels)
+
+
+def _head_shapes(width, policy_channels):
+    shapes = []
+    pc = head_channels(width, policy_channels, 2)
+    for i in range(2):
+        shapes.append((f"policy_head.layers.{2 * i}.weight", (pc[i + 1], pc[i], 3, 3)))
+    vc = head_channels(width, 1, 4)
+    for i in range(4):
+        shapes.append((f"value_head.layers.{2 * i}.weight", (vc[i + 1], vc[i], 3, 3)))
+    return shapes
+
+
+def synthetic_weights(seed, shapes, gain=1.0):
+    """name -> float32 array for any (name, shape) list, same rule as below."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, shape in shapes:
+        bound = gain / math.sqrt(shape[1] * shape[2] * shape[3])
+        out[name] = rs.uniform(-bound, bound, size=shape).astype(np.float32)
+    return out
+
+
 def synthetic_recurrent_net_weights(seed, in_channels, policy_channels, width=64,
                                     num_blocks=2, recall=True, gain=1.0):
     """name -> float32 array, drawn from ``np.random.RandomState(seed)`` in

@@ -101,3 +101,51 @@ class RecurrentNetRef:
         finally:
             torch.set_num_threads(n)
         return p.numpy(), v.numpy()
+
+
+def _heads(w, trunk, value_activation):
+    """Reduce_PolicyHead + Reduce_ValueHead (blocks.py:46-92,130-170) on the trunk output."""
+    conv = lambda x, name: F.conv2d(x, w[name], None, 1, "same")
+    p = F.relu(conv(trunk, "policy_head.layers.0.weight"))
+    p = conv(p, "policy_head.layers.2.weight")
+    act = torch.tanh if value_activation == "tanh" else F.relu
+    v = trunk
+    for i in range(4):
+        v = conv(v, f"value_head.layers.{2 * i}.weight")
+        if i != 3:
+            v = act(v)
+    return p, torch.tanh(v.mean(dim=(1, 2, 3)).reshape(-1, 1))
+
+
+class FeedForwardRef:
+    """ResNet / ConvNet with hex=False (Architectures/ResNet.py:64-70, ConvNet.py:52-57)."""
+
+    def __init__(self, weights, arch, num_blocks, value_activation="tanh"):
+        self.w = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in weights.items()}
+        self.arch, self.num_blocks, self.value_activation = arch, num_blocks, value_activation
+        self.recurrent = False
+
+    def forward(self, x):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        conv = lambda t, name: F.conv2d(t, self.w[name], None, 1, "same")
+        if self.arch == "resnet":
+            t = F.relu(conv(x, "input_block.0.weight"))
+            for b in range(self.num_blocks):
+                pre = f"residual_blocks.{b}.before_shortcut."
+                y = conv(F.relu(conv(t, pre + "0.weight")), pre + "2.weight")
+                t = F.relu(y + t)
+        else:
+            t = F.elu(conv(x, "general_module.0.weight"))
+            for i in range(self.num_blocks):
+                t = F.elu(conv(t, f"general_module.{2 * (i + 1)}.weight"))
+        return _heads(self.w, t, self.value_activation)
+
+    def inference(self, state, iters=None):
+        n = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            with torch.no_grad():
+                p, v = self.forward(state)
+        finally:
+            torch.set_num_threads(n)
+        return p.numpy(), v.numpy()

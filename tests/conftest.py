@@ -51,3 +51,18 @@ def full_table(net_kat, name):
     t[codes, :9] = net_kat[f"{name}_i2_probs"]
     t[codes, 9] = net_kat[f"{name}_i2_value"]
     return t
+
+
+@pytest.fixture(scope="session")
+def net_kat2():
+    return dict(np.load(os.path.join(GOLDEN, "net_kat2.npz")))
+
+
+NETS2 = {"D": ("resnet", 3, 32, 3, 3, 2.0), "E": ("convnet", 4, 32, 3, 3, 2.0), "F": ("convnet", 5, 48, 2, 1, 2.0)}
+
+
+def nets2_weights(name):
+    from nuzero_amd.weights import synthetic_weights, resnet_param_shapes, convnet_param_shapes
+    arch, seed, width, depth, k, gain = NETS2[name]
+    shapes = resnet_param_shapes(2, 1, width, depth) if arch == "resnet" else convnet_param_shapes(2, 1, k, width, depth)
+    return synthetic_weights(seed, shapes, gain)

@@ -56,8 +56,11 @@ from Search.Node import Node  # noqa: E402
 from Games.Tic_Tac_Toe.tic_tac_toe import tic_tac_toe  # noqa: E402
 from Neural_Networks.Network_Manager import Network_Manager  # noqa: E402
 from Neural_Networks.Architectures.RecurrentNet import RecurrentNet  # noqa: E402
+from Neural_Networks.Architectures.ResNet import ResNet  # noqa: E402
+from Neural_Networks.Architectures.ConvNet import ConvNet  # noqa: E402
 
-from nuzero_amd.weights import synthetic_recurrent_net_weights  # noqa: E402
+from nuzero_amd.weights import (synthetic_recurrent_net_weights, synthetic_weights,  # noqa: E402
+                                resnet_param_shapes, convnet_param_shapes)
 
 tic_tac_toe.generate_network_input = tic_tac_toe.generate_state_image  # HEAD drift shim
 torch.set_num_threads(1)
@@ -218,6 +221,42 @@ def gen_nets(reach):
     out["batch7_index"] = np.arange(len(codes))[::600][:7].astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "net_kat.npz"), **out)
     return codes, tables
+
+
+# non-recurrent square nets: name -> (arch, seed, width, depth, kernel_size, gain)
+NETS2 = {
+    "D": ("resnet", 3, 32, 3, 3, 2.0),
+    "E": ("convnet", 4, 32, 3, 3, 2.0),
+    "F": ("convnet", 5, 48, 2, 1, 2.0),
+}
+
+
+def gen_nets2(reach):
+    """ResNet / ConvNet with hex=False through Network_Manager.inference's non-recurrent branch."""
+    codes = np.array(sorted(k for k, t in reach.items() if not t), np.int32)[::9]
+    out = {"codes": codes}
+    for name, (arch, seed, width, depth, k, gain) in NETS2.items():
+        if arch == "resnet":
+            w = synthetic_weights(seed, resnet_param_shapes(2, 1, width, depth), gain)
+            net = ResNet(2, 1, num_filters=width, num_blocks=depth, hex=False)
+        else:
+            w = synthetic_weights(seed, convnet_param_shapes(2, 1, k, width, depth), gain)
+            net = ConvNet(2, 1, kernel_size=k, num_filters=width, num_layers=depth, hex=False)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(w.keys()), (list(sd.keys()), list(w.keys()))
+        net.load_state_dict({kk: torch.from_numpy(v) for kk, v in w.items()})
+        nm = Network_Manager(net)
+        logits = np.zeros((len(codes), 9), np.float32)
+        probs = np.zeros((len(codes), 9), np.float32)
+        vals = np.zeros((len(codes),), np.float32)
+        g = tic_tac_toe()
+        for i, c in enumerate(codes):
+            set_board(g, int(c))
+            p, v = nm.inference(g.generate_network_input(), False)
+            logits[i], probs[i], vals[i] = p.numpy().reshape(-1), softmax(p).reshape(-1), v.item()
+        out[f"{name}_logits"], out[f"{name}_probs"], out[f"{name}_value"] = logits, probs, vals
+    np.savez_compressed(os.path.join(HERE, "net_kat2.npz"), **out)
+    return {k: list(v) for k, v in NETS2.items()}
 
 
 # --------------------------------------------------------------------------- search
@@ -412,6 +451,9 @@ def gen_unit():
 
 
 def main():
+    if "--only-nets2" in sys.argv:          # added later; leaves the other fixtures byte-identical
+        print(json.dumps(gen_nets2(reachable()), indent=1))
+        return
     meta = {"numpy": np.__version__, "scipy": scipy.__version__, "torch": torch.__version__,
             "python": sys.version.split()[0],
             "shims": ["termcolor stand-in", "hexagdly stand-in (hex=False only)",
@@ -421,6 +463,7 @@ def main():
     meta["rng"] = gen_rng()
     reach = reachable()
     codes, tables = gen_nets(reach)
+    meta["nets2"] = gen_nets2(reach)
     meta["search"] = gen_search(codes, tables)
     meta["unit"] = gen_unit()
     with open(os.path.join(HERE, "meta.json"), "w") as f:

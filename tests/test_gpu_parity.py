@@ -412,3 +412,35 @@ def test_evaluation_match_between_two_mcts_agents(net_kat, sims1, tab1, sims2, t
     assert np.array_equal(r1["actions"], r2["actions"])
     e1.close()
     e2.close()
+
+
+@pytest.mark.parametrize("name", ["D", "E", "F"])
+def test_feedforward_networks_match_reference(net_kat2, name):
+    """ResNet and ConvNet (hex=False; 3x3 and 1x1 trunks, ELU) on the fused kernel vs the reference
+    classes' outputs: priors and values within 1e-5; and a fused search against the C oracle."""
+    from conftest import NETS2, nets2_weights
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import cref
+    arch, seed, width, depth, k, gain = NETS2[name]
+    w = nets2_weights(name)
+    nm = Network_Manager(w)
+    s = nm.spec()
+    assert (s.arch, s.width, s.num_blocks, s.kernel_size) == (arch, width, depth, k) and not nm.is_recurrent()
+    codes = net_kat2["codes"]
+    p, v = nm.inference(_images(codes), False)
+    want_l = net_kat2[f"{name}_logits"]
+    np.testing.assert_allclose(p.cpu().numpy().reshape(-1, 9), want_l, atol=2e-6 * max(1.0, np.abs(want_l).max()))
+    np.testing.assert_allclose(v.cpu().numpy().reshape(-1), net_kat2[f"{name}_value"], atol=1e-5)
+    cfg = legacy_ttt_search_config(40)
+    eng = _engine(cfg, 24)
+    eng.set_weights(w, width=width, num_blocks=depth, arch=arch, kernel_size=k)
+    _, _, probs = eng.net_forward(_images(codes))
+    np.testing.assert_allclose(probs.cpu().numpy(), net_kat2[f"{name}_probs"], atol=1e-5)
+    table = _gpu_table(eng)
+    eng.play(base_seed=9)
+    r = eng.export(trace=True)
+    o = cref.play_games(table, cfg, [9 + g for g in range(24)])
+    for key in ("lengths", "outcomes", "actions", "visits", "child_prior", "child_value_sum"):
+        assert np.array_equal(r[key], o[key]), key
+    eng.close()

@@ -181,3 +181,19 @@ def test_c_oracle_against_reference(search_kat, net_kat):
                 assert r["visits"][g, m][mv["child_actions"]].tolist() == mv["child_visits"]
                 assert r["child_prior"][g, m][mv["child_actions"]].tolist() == mv["child_priors"]
                 assert r["child_value_sum"][g, m][mv["child_actions"]].tolist() == mv["child_value_sums"]
+
+
+@pytest.mark.parametrize("name", ["D", "E", "F"])
+def test_feedforward_nets_against_reference(net_kat2, name):
+    """ResNet / ConvNet (hex=False) oracle vs the reference classes' outputs, bit for bit at batch 1."""
+    from conftest import NETS2, nets2_weights
+    from oracle.net import FeedForwardRef
+    arch, seed, width, depth, k, gain = NETS2[name]
+    net = FeedForwardRef(nets2_weights(name), arch, depth)
+    codes = net_kat2["codes"]
+    for j in range(0, len(codes), 25):
+        g = ottt.TicTacToe()
+        g.board = ottt.board_from_code(int(codes[j]))
+        p, v = net.inference(g.state_image())
+        assert np.array_equal(p.reshape(-1), net_kat2[f"{name}_logits"][j])
+        assert np.float32(v.reshape(-1)[0]) == net_kat2[f"{name}_value"][j]
