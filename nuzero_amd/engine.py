@@ -77,11 +77,30 @@ class SelfPlayEngine:
                 torch.cuda.synchronize(t.device)
         check(lib.nz_engine_set_weights(self._h, byref(nd), ptrs, len(tensors), int(recurrent_iterations)), self._h)
         self.net_spec = dict(width=width, num_blocks=num_blocks, recall=recall, iters=recurrent_iterations)
+        self.position_cache = False
 
     def set_table(self, table):
         """Test hook: [19683, 10] float32 table evaluator (9 probs + value)."""
         t = np.ascontiguousarray(table, dtype=np.float32)
         check(lib.nz_engine_set_table(self._h, t.ctypes.data_as(c_void_p), int(t.shape[0])), self._h)
+
+    def cache_all_positions(self):
+        """Inference cache for Tic-Tac-Toe (the reference's optional Cache, Utils/Caches, used at
+        Explorer.py:146-155): the game has only 3^9 position codes, so instead of memoising leaf by
+        leaf the network is evaluated ONCE on every code and the search then reads (softmax probs,
+        value) from that table -- a cache with a 100 % hit ratio and the same results as no cache.
+        Call again after set_weights.  bench.py never uses it (it would skip the measured work)."""
+        if self.net_spec is None:
+            raise RuntimeError("set_weights first")
+        codes = torch.arange(3 ** 9, device=self.device)
+        pw = 3 ** torch.arange(9, device=self.device)
+        cells = (codes[:, None] // pw[None, :]) % 3                       # [N, 9] in {0,1,2}
+        x = torch.stack([(cells == 1), (cells == 2)], 1).to(torch.float32).reshape(-1, 2, 3, 3)
+        _, value, probs = self.net_forward(x)
+        table = torch.cat([probs, value[:, None]], 1).contiguous()
+        torch.cuda.synchronize(self.device)
+        check(lib.nz_engine_set_table(self._h, _ptr(table), int(table.shape[0])), self._h)
+        self.position_cache = True
 
     def net_flops_per_position(self):
         v = c_double(0)

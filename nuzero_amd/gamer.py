@@ -48,10 +48,14 @@ class GameRecord:
 
 class DisabledCache:
     """Cache-shaped object for callers that expect one back from play_game
-    (AlphaZero.py:553-568); the engine evaluates every leaf."""
+    (AlphaZero.py:553-568).  hit_ratio 0: the engine evaluates every leaf; 1: every leaf is
+    read from the all-positions table (SelfPlayEngine.cache_all_positions)."""
+
+    def __init__(self, hit_ratio=0.0):
+        self.hit_ratio = hit_ratio
 
     def get_hit_ratio(self):
-        return 0.0
+        return self.hit_ratio
 
     def length(self):
         return 0
@@ -94,8 +98,9 @@ class Gamer:
         name = getattr(game_class, "__name__", str(game_class)).lower()
         if "tic" not in name and "ttt" not in name:
             raise NotImplementedError(f"game {name!r}: only Tic_Tac_Toe runs on the GPU engine so far")
-        if cache_choice not in ("disabled", None):
-            raise NotImplementedError("inference caches are not used by the GPU engine (cache_choice='disabled')")
+        if cache_choice not in ("disabled", None, "dict", "keyless"):
+            raise ValueError(f"bad cache_choice {cache_choice!r}")          # general_utils.py:14-24
+        self.cache_choice = cache_choice if cache_choice else "disabled"
         self.buffer, self.shared_storage = buffer, shared_storage
         self.game_index = game_index
         self.search_config = search_config
@@ -122,6 +127,8 @@ class Gamer:
                                     value_activation=s.value_activation,
                                     recurrent_iterations=self.recurrent_iterations, arch=s.arch,
                                     kernel_size=s.kernel_size)
+            if self.cache_choice != "disabled":
+                self.engine.cache_all_positions()
             self._loaded = nm
         self.engine.play(base_seed=self.base_seed)
         self.base_seed += self.num_games
@@ -138,7 +145,7 @@ class Gamer:
         """Reference signature (Gamer.py:39-97): (stats, cache).  With num_games > 1
         the stats are those of the round's first game; use play_games for all."""
         _, stats = self.play_games()
-        return stats[0], DisabledCache()
+        return stats[0], DisabledCache(0.0 if self.cache_choice == "disabled" else 1.0)
 
     def play_forever(self):
         while not self.time_to_stop:
