@@ -1,0 +1,70 @@
+"""oracle/scs.py against the SCS golden vectors made from the genuine reference
+(tests/golden/make_golden_scs.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.scs import ScsConfig, ScsGame
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CONFIGS = {
+    "mirrored5": None,    # the reference's own mirrored_config_5.yml: restated below as data
+    "late_reinf": os.path.join(GOLDEN, "scs_configs", "late_reinforcements_5x5.yml"),
+    "ten_by_ten": os.path.join(GOLDEN, "scs_configs", "ten_by_ten.yml"),
+    "two_types": os.path.join(GOLDEN, "scs_configs", "two_types_6x5.yml"),
+}
+
+
+@pytest.fixture(scope="module")
+def kat():
+    return dict(np.load(os.path.join(GOLDEN, "scs_kat.npz")))
+
+
+def checksum_weights(n):
+    i = np.arange(n, dtype=np.int64)
+    return ((i * 2654435761) % 1000003).astype(np.float64) / 1000003.0
+
+
+@pytest.mark.parametrize("name", ["late_reinf", "ten_by_ten", "two_types", "mirrored5"])
+def test_scs_rules_against_reference(kat, name):
+    path = CONFIGS[name] or os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsConfig(path)
+    planes, rows, cols, channels, stacking, turns = kat[f"{name}_shape"]
+    assert (cfg.planes, cfg.rows, cfg.cols, cfg.channels, cfg.stacking, cfg.turns) == (planes, rows, cols, channels,
+                                                                                       stacking, turns)
+    game_ids, actions = kat[f"{name}_game"], kat[f"{name}_action"]
+    legal, n_legal = kat[f"{name}_legal"], kat[f"{name}_n_legal"]
+    images = {int(s): img for s, img in zip(kat[f"{name}_image_step"], kat[f"{name}_images"])}
+    w = checksum_weights(channels * rows * cols)
+    pos = 0
+    g, last = None, -1
+    n_images = 0
+    for i in range(len(actions)):
+        if game_ids[i] != last:
+            if g is not None:
+                _check_end(kat, name, last, g, images)
+            g, last = ScsGame(cfg), int(game_ids[i])
+        assert not g.is_terminal()
+        assert (g.player, g.sub_phase, g.stage, g.turn) == (kat[f"{name}_player"][i], kat[f"{name}_sub_phase"][i],
+                                                           kat[f"{name}_stage"][i], kat[f"{name}_turn"][i]), i
+        mask = g.possible_actions()
+        assert mask.dtype == np.int8 and mask.shape == (planes, rows, cols)
+        idx = np.nonzero(mask.flatten())[0]
+        assert idx.tolist() == legal[pos:pos + n_legal[i]].tolist(), i
+        pos += n_legal[i]
+        img = g.state_image()
+        assert img.dtype == np.float32 and img.shape == (1, channels, rows, cols)
+        assert float(np.sum(img.reshape(-1).astype(np.float64) * w)) == kat[f"{name}_checksum"][i], i
+        if i in images:
+            assert np.array_equal(img[0], images[i]), i
+            n_images += 1
+        g.step_index(int(actions[i]))
+    _check_end(kat, name, last, g, images)
+    assert n_images > 20
+
+
+def _check_end(kat, name, gi, g, images):
+    assert g.is_terminal()
+    assert g.get_length() == kat[f"{name}_lengths"][gi] and g.get_terminal_value() == kat[f"{name}_values"][gi]
+    assert np.array_equal(g.state_image()[0], images[-(gi + 1)])
