@@ -253,6 +253,43 @@ nz_status nz_engine_profile_read(nz_engine* e, double* ms_host /*[3]*/, int64_t*
  * times of the stamped build are not quoted. */
 nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out10_host);
 
+/* ---- SCS rules as batch operators ------------------------------------------
+ * Device-side state transition, legal-move mask and state image of the SCS hex
+ * war-game (Games/SCS/SCS_Game.py: step :375-391, possible_actions :395-484,
+ * update_game_env :687-831, resolve_combat :997-1044, generate_state :1348-1505),
+ * one independent game per batch row.  The search is not built on them yet; they
+ * exist so that the rules can be checked against the oracle step by step.
+ * A game is described by plain arrays (what load_game_from_config, :1570-1779,
+ * reads from the YAML file, "Detailed" map / victory points only):
+ *   terrain  float[rows*cols][3]  attack modifier, defense modifier, movement cost
+ *   vp       int32[n_vp[0]+n_vp[1]][2]  (row, col), player one's points first
+ *   units    int32[n_units][5]  player (0/1), arrival turn, attack, defense, movement;
+ *            in schedule order: player one's turns 0..T, then player two's
+ *   arrival  uint8[n_units][rows*cols]  1 where the unit may be placed            */
+typedef struct nz_scs nz_scs;
+typedef struct nz_scs_desc {
+  int32_t rows, cols, turns, stacking;
+  const float* terrain;
+  int32_t n_vp[2];
+  const int32_t* vp;
+  int32_t n_units;
+  const int32_t* units;
+  const uint8_t* arrival;
+} nz_scs_desc;
+nz_status nz_scs_create(nz_scs** out, const nz_scs_desc* desc, int32_t n_games, int32_t device);
+void nz_scs_destroy(nz_scs* h);
+const char* nz_scs_last_error(const nz_scs* h);
+nz_status nz_scs_dims(const nz_scs* h, int32_t* planes, int32_t* rows, int32_t* cols, int32_t* channels);
+nz_status nz_scs_reset(nz_scs* h, void* stream);
+/* actions_dev int32[G]: flat action index (plane, row, col) or -1 to leave the game as it is */
+nz_status nz_scs_step(nz_scs* h, const int32_t* actions_dev, void* stream);
+/* mask_dev int8[G][planes*rows*cols]; all zero for a finished game */
+nz_status nz_scs_legal_mask(nz_scs* h, int8_t* mask_dev, void* stream);
+/* image_dev float[G][channels][rows][cols] = generate_state() */
+nz_status nz_scs_state_image(nz_scs* h, float* image_dev, void* stream);
+/* status_dev int32[G][7]: player, sub_phase, stage, turn, terminal, terminal_value, length */
+nz_status nz_scs_status(nz_scs* h, int32_t* status_dev, void* stream);
+
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream
  * (Explorer.py:77-78,89,199,208). */

@@ -48,6 +48,12 @@ class Dims(Structure):
                 ("node_capacity", c_int32)]
 
 
+class ScsDesc(Structure):
+    _fields_ = [("rows", c_int32), ("cols", c_int32), ("turns", c_int32), ("stacking", c_int32),
+                ("terrain", c_void_p), ("n_vp", c_int32 * 2), ("vp", c_void_p), ("n_units", c_int32),
+                ("units", c_void_p), ("arrival", c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/nuzero_amd.h declares
 SIGNATURES = {
     "nz_version": (c_char_p, []),
@@ -80,6 +86,15 @@ SIGNATURES = {
     "nz_engine_profile": (c_int32, [c_void_p, c_int32]),
     "nz_engine_profile_read": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_int64), POINTER(c_int64)]),
     "nz_engine_phase_stamps": (c_int32, [c_void_p, c_int32, POINTER(c_double)]),
+    "nz_scs_create": (c_int32, [POINTER(c_void_p), POINTER(ScsDesc), c_int32, c_int32]),
+    "nz_scs_destroy": (None, [c_void_p]),
+    "nz_scs_last_error": (c_char_p, [c_void_p]),
+    "nz_scs_dims": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
+    "nz_scs_reset": (c_int32, [c_void_p, c_void_p]),
+    "nz_scs_step": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_legal_mask": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_state_image": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_status": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

@@ -1,0 +1,337 @@
+// SCS (hex war-game) rules on the device: state transition, legal-move mask, state image.
+//
+// Restates Games/SCS/SCS_Game.py of the reference: the 10-stage turn machine (:687-831),
+// possible_actions (:395-484), parse/play_action (:486-633), end_movement / end_fighting
+// (:927-946), resolve_combat (:997-1044, :1253-1285), the hex neighbourhood with column-parity
+// offsets (:1048-1094, :1199-1243), check_termination (:857-894), generate_state (:1348-1505).
+//
+// The reference keeps Python object lists; what its results depend on is
+//   * the order of the units on a tile (stacking level = list index, Tile.py:24-28),
+//   * the order in which attackers were selected (get_strongest_attacker walks that list),
+//   * the reinforcement queues' schedule order (pop(0)),
+// while the available / moved / attacked lists only matter as sets.  So a game is a flat
+// record: per unit {status, tile, movement points}, per tile an ordered stack of unit ids and
+// an owner, the ordered attacker list, the target tile and the turn-machine registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nz {
+
+constexpr int SCS_MAX_TILES = 100;    // 10 x 10
+constexpr int SCS_MAX_STACK = 3;
+constexpr int SCS_MAX_UNITS = 32;
+constexpr int SCS_MAX_TURNS = 16;
+
+// unit status: queued (not yet placed), the reference's 0/1/2, destroyed
+enum : int8_t { SCS_QUEUED = -1, SCS_AVAILABLE = 0, SCS_MOVED = 1, SCS_ATTACKED = 2, SCS_DEAD = 3 };
+
+struct ScsRules {                     // immutable game description (one per engine, device memory)
+  int32_t rows, cols, tiles, turns, stacking, n_units, planes, channels;
+  int32_t placement_limit, movement_limit, target_limit, attackers_limit, confirm_limit, no_move_limit,
+      no_fight_limit;
+  int8_t neighbour[SCS_MAX_TILES][6];          // n, ne, se, s, sw, nw; -1 = off board
+  float terrain_f[SCS_MAX_TILES][3];           // attack modifier, defense modifier, cost as float32 (image)
+  double attack_mod[SCS_MAX_TILES], defense_mod[SCS_MAX_TILES];
+  int32_t cost[SCS_MAX_TILES];
+  int32_t n_vp[2];
+  int8_t vp[2][SCS_MAX_TILES];
+  // units in schedule order: player 0's turn 0 .. turn T, then player 1's
+  int8_t u_player[SCS_MAX_UNITS], u_turn[SCS_MAX_UNITS], u_attack[SCS_MAX_UNITS], u_defense[SCS_MAX_UNITS],
+      u_mov[SCS_MAX_UNITS];
+  uint8_t arrival[SCS_MAX_UNITS][SCS_MAX_TILES];
+};
+
+struct ScsState {
+  int16_t stage, turn, length;
+  int8_t player, sub_phase, terminal, terminal_value, target, n_attackers;
+  int8_t attackers[SCS_MAX_UNITS];
+  int8_t status[SCS_MAX_UNITS], tile[SCS_MAX_UNITS], mov[SCS_MAX_UNITS];
+  int8_t stack_n[SCS_MAX_TILES], owner[SCS_MAX_TILES];
+  int8_t stack[SCS_MAX_TILES][SCS_MAX_STACK];
+};
+
+struct Scs {
+  const ScsRules& r;
+  ScsState& s;
+  __device__ Scs(const ScsRules& rules, ScsState& state) : r(rules), s(state) {}
+
+  // ---- helpers ------------------------------------------------------------------------------
+  __device__ int level_of(int u) const {                 // Tile.get_stacking_level
+    const int t = s.tile[u];
+    for (int i = 0; i < s.stack_n[t]; ++i)
+      if (s.stack[t][i] == u) return i;
+    return 0;
+  }
+  __device__ void place(int u, int t) {                  // Tile.place_unit
+    s.owner[t] = r.u_player[u];
+    s.stack[t][s.stack_n[t]++] = (int8_t)u;
+  }
+  __device__ void remove(int u, int t) {                 // Tile.remove_unit
+    if (s.stack_n[t] == 1) s.owner[t] = -1;
+    int i = 0;
+    while (s.stack[t][i] != u) ++i;
+    for (; i + 1 < s.stack_n[t]; ++i) s.stack[t][i] = s.stack[t][i + 1];
+    --s.stack_n[t];
+  }
+  __device__ int count(int player, int status) const {
+    int n = 0;
+    for (int u = 0; u < r.n_units; ++u) n += (r.u_player[u] == player && s.status[u] == status);
+    return n;
+  }
+  __device__ int queue_head(int player, int turn) const {   // current_reinforcements[player][turn][0] or -1
+    for (int u = 0; u < r.n_units; ++u)
+      if (r.u_player[u] == player && r.u_turn[u] == turn && s.status[u] == SCS_QUEUED) return u;
+    return -1;
+  }
+  __device__ bool can_move(int u, int dir, bool consider_units) const {   // check_mobility (:1096-1111)
+    const int n = r.neighbour[s.tile[u]][dir];
+    if (n < 0) return false;
+    if (s.mov[u] - r.cost[n] < 0) return false;
+    if (consider_units && (s.stack_n[n] == r.stacking || s.owner[n] == (r.u_player[u] ^ 1))) return false;
+    return true;
+  }
+  __device__ bool enemy_adjacent(int t, int enemy) const {   // len(check_adjacent_units) > 0
+    for (int d = 0; d < 6; ++d) {
+      const int n = r.neighbour[t][d];
+      if (n < 0) continue;
+      for (int i = 0; i < s.stack_n[n]; ++i)
+        if (r.u_player[s.stack[n][i]] == enemy) return true;
+    }
+    return false;
+  }
+  __device__ void end_fighting(int u) { s.status[u] = SCS_ATTACKED; }              // (:942-946)
+  __device__ void end_movement(int u) {                                            // (:927-940)
+    s.status[u] = SCS_MOVED;
+    if (!enemy_adjacent(s.tile[u], r.u_player[u] ^ 1)) end_fighting(u);
+  }
+  __device__ void destroy(int u) {                                                 // (:982-995)
+    remove(u, s.tile[u]);
+    s.status[u] = SCS_DEAD;
+  }
+  // first strict maximum of (k1, k2, movement allowance) in list order (:1253-1285)
+  __device__ int strongest(const int8_t* list, int n, bool attacker) const {
+    int best = list[0];
+    for (int i = 0; i < n; ++i) {
+      const int u = list[i];
+      const int a1 = attacker ? r.u_attack[u] : r.u_defense[u], b1 = attacker ? r.u_attack[best] : r.u_defense[best];
+      const int a2 = attacker ? r.u_defense[u] : r.u_attack[u], b2 = attacker ? r.u_defense[best] : r.u_attack[best];
+      if (a1 > b1 || (a1 == b1 && (a2 > b2 || (a2 == b2 && r.u_mov[u] > r.u_mov[best])))) best = u;
+    }
+    return best;
+  }
+  __device__ void resolve_combat() {                                               // (:997-1044)
+    const int t = s.target;
+    double total_defense = 0.0;
+    int dsum = 0;
+    for (int i = 0; i < s.stack_n[t]; ++i) dsum += r.u_defense[s.stack[t][i]];
+    total_defense = (double)dsum * r.defense_mod[t];
+    double total_attack = 0.0;
+    for (int i = 0; i < s.n_attackers; ++i) {
+      const int u = s.attackers[i];
+      total_attack = total_attack + (double)r.u_attack[u] * r.attack_mod[s.tile[u]];
+      end_fighting(u);
+    }
+    if (total_attack <= total_defense) destroy(strongest(s.attackers, s.n_attackers, true));
+    if (total_attack >= total_defense) destroy(strongest(s.stack[t], s.stack_n[t], false));
+  }
+  __device__ void new_turn() {                                                     // (:845-855)
+    for (int u = 0; u < r.n_units; ++u)
+      if (s.status[u] == SCS_ATTACKED) {
+        s.status[u] = SCS_AVAILABLE;
+        s.mov[u] = r.u_mov[u];
+      }
+  }
+  __device__ void check_termination() {                                            // (:857-894)
+    int p1_cap = 0, p2_cap = 0;
+    for (int i = 0; i < r.n_vp[0]; ++i) p2_cap += s.owner[r.vp[0][i]] == 1;
+    for (int i = 0; i < r.n_vp[1]; ++i) p1_cap += s.owner[r.vp[1][i]] == 0;
+    const double a = (double)p1_cap / (double)r.n_vp[1], b = (double)p2_cap / (double)r.n_vp[0];
+    s.terminal_value = a > b ? 1 : (a < b ? -1 : 0);
+  }
+  __device__ void update_env() {                                                   // update_game_env (:687-831)
+    int stage = s.stage;
+    bool done = false;
+    for (;;) {
+      if (stage == -2) {
+        if (queue_head(0, s.turn) < 0) { ++stage; continue; }
+      } else if (stage == -1) {
+        if (queue_head(1, s.turn) < 0) { ++s.turn; ++stage; continue; }
+      } else if (stage == 0 || stage == 4) {
+        if (queue_head(stage >> 2, s.turn) < 0) { ++stage; continue; }
+      } else if (stage == 1 || stage == 5) {
+        if (count(stage >> 2, SCS_AVAILABLE) == 0) { ++stage; continue; }
+      } else if (stage == 2) {
+        if (count(0, SCS_MOVED) == 0) { stage = 4; continue; }
+        if (s.target >= 0) { ++stage; continue; }
+      } else if (stage == 6) {
+        if (count(1, SCS_MOVED) == 0) {
+          if (s.turn + 1 > r.turns) { done = true; break; }
+          ++s.turn;
+          stage = 0;
+          new_turn();
+          continue;
+        }
+        if (s.target >= 0) { ++stage; continue; }
+      } else {   // 3, 7
+        if (s.target < 0) { --stage; continue; }
+      }
+      break;
+    }
+    s.player = (stage == -2 || (stage >= 0 && stage <= 3)) ? 0 : 1;
+    if (done) {
+      s.terminal = 1;
+      check_termination();
+    }
+    s.sub_phase = (stage == -2 || stage == -1 || stage == 0 || stage == 4) ? 0
+                  : (stage == 1 || stage == 5) ? 1 : (stage == 2 || stage == 6) ? 2 : 3;
+    s.stage = (int16_t)stage;
+  }
+
+  // ---- public operations ----------------------------------------------------------------------
+  __device__ void reset() {
+    s.stage = -2; s.turn = 0; s.length = 0;
+    s.player = 0; s.sub_phase = 0; s.terminal = 0; s.terminal_value = 0; s.target = -1; s.n_attackers = 0;
+    for (int u = 0; u < SCS_MAX_UNITS; ++u) { s.status[u] = SCS_QUEUED; s.tile[u] = 0; s.mov[u] = u < r.n_units ? r.u_mov[u] : 0; s.attackers[u] = 0; }
+    for (int t = 0; t < SCS_MAX_TILES; ++t) {
+      s.stack_n[t] = 0; s.owner[t] = -1;
+      for (int i = 0; i < SCS_MAX_STACK; ++i) s.stack[t][i] = -1;
+    }
+    update_env();
+  }
+
+  // calls f(action_index) for every legal action (possible_actions, :395-484); order is irrelevant
+  template <typename F>
+  __device__ void for_each_legal(F&& f) const {
+    const int p = s.player, S = r.stacking, T = r.tiles;
+    if (s.sub_phase == 0) {
+      const int u = queue_head(p, s.turn);
+      for (int t = 0; t < T; ++t)
+        if (r.arrival[u][t] && !(s.owner[t] == (p ^ 1) || s.stack_n[t] == S)) f(t);
+    } else if (s.sub_phase == 1) {
+      for (int u = 0; u < r.n_units; ++u) {
+        if (r.u_player[u] != p || s.status[u] != SCS_AVAILABLE) continue;
+        const int t = s.tile[u], lvl = level_of(u);
+        f((r.confirm_limit + lvl) * T + t);
+        for (int d = 0; d < 6; ++d)
+          if (can_move(u, d, true)) f((r.placement_limit + d * S + lvl) * T + t);
+      }
+    } else if (s.sub_phase == 2) {
+      for (int u = 0; u < r.n_units; ++u) {
+        if (r.u_player[u] != p || s.status[u] != SCS_MOVED) continue;
+        const int t = s.tile[u];
+        f((r.no_move_limit + level_of(u)) * T + t);
+        for (int d = 0; d < 6; ++d) {
+          const int n = r.neighbour[t][d];
+          if (n < 0) continue;
+          for (int i = 0; i < s.stack_n[n]; ++i)
+            if (r.u_player[s.stack[n][i]] == (p ^ 1)) { f(r.movement_limit * T + n); break; }
+        }
+      }
+    } else {
+      for (int d = 0; d < 6; ++d) {
+        const int n = r.neighbour[s.target][d];
+        if (n < 0) continue;
+        for (int i = 0; i < s.stack_n[n]; ++i) {
+          const int u = s.stack[n][i];
+          if (r.u_player[u] != p || s.status[u] == SCS_ATTACKED) continue;
+          bool chosen = false;
+          for (int k = 0; k < s.n_attackers; ++k) chosen |= s.attackers[k] == u;
+          if (!chosen) f((r.target_limit + i) * T + n);
+        }
+      }
+      if (s.n_attackers > 0) f(r.attackers_limit * T + s.target);
+    }
+  }
+
+  __device__ void step(int action) {                                               // step (:375-391)
+    const int T = r.tiles, S = r.stacking;
+    const int plane = action / T, t = action % T;
+    if (plane < r.placement_limit) {
+      const int u = queue_head(s.player, s.turn);
+      s.status[u] = SCS_AVAILABLE;
+      s.tile[u] = (int8_t)t;
+      place(u, t);
+    } else if (plane < r.movement_limit) {
+      const int idx = plane - r.placement_limit, lvl = idx % S, dir = idx / S;
+      const int u = s.stack[t][lvl], dest = r.neighbour[t][dir];
+      s.mov[u] = (int8_t)(s.mov[u] - r.cost[dest]);
+      s.tile[u] = (int8_t)dest;
+      place(u, dest);
+      remove(u, t);
+      bool any = false;
+      for (int d = 0; d < 6; ++d) any |= can_move(u, d, false);
+      if (!any) end_movement(u);
+    } else if (plane < r.target_limit) {
+      s.target = (int8_t)t;
+    } else if (plane < r.attackers_limit) {
+      s.attackers[s.n_attackers++] = s.stack[t][plane - r.target_limit];
+    } else if (plane < r.confirm_limit) {
+      resolve_combat();
+      s.target = -1;
+      s.n_attackers = 0;
+    } else if (plane < r.no_move_limit) {
+      end_movement(s.stack[t][plane - r.confirm_limit]);
+    } else {
+      end_fighting(s.stack[t][plane - r.no_move_limit]);
+    }
+    ++s.length;
+    update_env();
+  }
+
+  // generate_state (:1348-1505); img is [channels][tiles] float32, fully written
+  __device__ void state_image(float* __restrict__ img) const {
+    const int T = r.tiles, S = r.stacking;
+    for (int i = 0; i < r.channels * T; ++i) img[i] = 0.0f;
+    for (int t = 0; t < T; ++t)
+      for (int k = 0; k < 3; ++k) img[k * T + t] = r.terrain_f[t][k];
+    for (int p = 0; p < 2; ++p)
+      for (int i = 0; i < r.n_vp[p]; ++i) img[(3 + p) * T + r.vp[p][i]] = 1.0f;
+    int base = 5;
+    for (int p = 0; p < 2; ++p) {
+      int shown = 0;
+      for (int u = 0; u < r.n_units && shown < 3; ++u) {       // schedule order = turn order within a player
+        if (r.u_player[u] != p || s.status[u] != SCS_QUEUED) continue;
+        const double importance = (double)((r.turns + 1) - (r.u_turn[u] - s.turn)) / (double)(r.turns + 1);
+        const int o = base + p * 18 + shown * 6;
+        for (int t = 0; t < T; ++t) {
+          if (r.arrival[u][t]) {
+            img[o * T + t] = (float)r.u_attack[u];
+            img[(o + 1) * T + t] = (float)r.u_defense[u];
+            img[(o + 2) * T + t] = (float)s.mov[u];
+          }
+          img[(o + 3) * T + t] = img[(o + 4) * T + t] = img[(o + 5) * T + t] = (float)importance;
+        }
+        ++shown;
+      }
+    }
+    base += 36;
+    const int per_player = 3 * S * 3;
+    for (int u = 0; u < r.n_units; ++u) {
+      const int st = s.status[u];
+      if (st < SCS_AVAILABLE || st > SCS_ATTACKED) continue;
+      const int o = base + r.u_player[u] * per_player + st * S * 3 + level_of(u) * 3, t = s.tile[u];
+      img[o * T + t] = (float)r.u_attack[u];
+      img[(o + 1) * T + t] = (float)r.u_defense[u];
+      img[(o + 2) * T + t] = (float)s.mov[u];
+    }
+    base += 2 * per_player;
+    if (s.target >= 0) img[base * T + s.target] = 1.0f;
+    base += 1;
+    for (int i = 0; i < s.n_attackers; ++i) {
+      const int u = s.attackers[i];
+      if (s.status[u] == SCS_DEAD) continue;
+      img[(base + level_of(u)) * T + s.tile[u]] = 1.0f;
+    }
+    base += S;
+    const float turn_v = (float)((double)s.turn / (double)r.turns);
+    const float player_v = s.player == 1 ? -1.0f : 1.0f;
+    for (int t = 0; t < T; ++t) {
+      img[(base + s.sub_phase) * T + t] = 1.0f;
+      img[(base + 4) * T + t] = turn_v;
+      img[(base + 5) * T + t] = player_v;
+    }
+  }
+};
+
+}  // namespace nz
