@@ -10,6 +10,8 @@ tests/golden/make_golden_scs.py made by importing the genuine reference.
 Only "Detailed" maps / victory points are supported (the "Randomized" creation methods draw from
 the global numpy stream at load time, SCS_Game.py:1683-1738).
 """
+import copy
+
 import numpy as np
 import yaml
 
@@ -99,7 +101,31 @@ class ScsGame:
         self.attackers = []
         self.player, self.sub_phase, self.stage, self.turn = 0, 0, -2, 0
         self.length, self.terminal, self.terminal_value = 0, False, 0
+        self.state_history, self.child_policy = [], []
         self._update_env()
+
+    def shallow_clone(self):
+        """SCS_Game.shallow_clone (:1782-1793): everything but the four histories."""
+        hist = (self.state_history, self.child_policy)
+        self.state_history, self.child_policy = [], []
+        g = copy.deepcopy(self)
+        self.state_history, self.child_policy = hist
+        return g
+
+    def store_state(self, state):
+        self.state_history.append(state)
+
+    def store_search_statistics(self, root):                          # (:1517-1521)
+        total = sum(c.visit_count for c in root.children)
+        by_action = {c.action: c.visit_count for c in root.children}
+        self.child_policy.append([by_action[a] / total if a in by_action else 0
+                                  for a in range(self.cfg.num_actions)])
+
+    def get_state_from_history(self, i):
+        return self.state_history[i]
+
+    def make_target(self, i):                                          # (:1523-1528)
+        return (self.terminal_value, self.child_policy[i])
 
     # ---- board geometry (:1048-1094, :1199-1243): n, ne, se, s, sw, nw ---------------------
     def neighbours(self, pos):

@@ -142,6 +142,7 @@ class Explorer:
             node.terminal_value = game.get_terminal_value()
             return node.terminal_value
         probs_f32, value = evaluator(game)
+        value = float(value)                     # Explorer.py:162: predicted_value.item()
         self.counters.expansions += 1
         mask = game.possible_actions().flatten()
         probs = probs_f32.flatten() * mask

@@ -68,3 +68,31 @@ def _check_end(kat, name, gi, g, images):
     assert g.is_terminal()
     assert g.get_length() == kat[f"{name}_lengths"][gi] and g.get_terminal_value() == kat[f"{name}_values"][gi]
     assert np.array_equal(g.state_image()[0], images[-(gi + 1)])
+
+
+def test_scs_search_against_reference():
+    """oracle/search.py on oracle/scs.py vs MCTS games the genuine reference played on SCS
+    (float32 priors, float64 after root noise, players 0/1 so Q is never negated)."""
+    import gzip
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scs_eval import evaluate_image
+    from oracle import search as osearch
+    with gzip.open(os.path.join(GOLDEN, "scs_search_kat.json.gz"), "rt") as f:
+        kat = json.load(f)
+    files = {"mirrored_config_5.yml": "mirrored_5x5.yml"}
+    for name, case in kat.items():
+        cfg = ScsConfig(os.path.join(GOLDEN, "scs_configs", files.get(case["config_file"], case["config_file"])))
+        ev = lambda game: evaluate_image(game.state_image()[0], cfg.num_actions)
+        for ref in case["games"]:
+            game = ScsGame(cfg)
+            trace = []
+            osearch.play_game(game, ev, case["config"], np.random.RandomState(ref["seed"]),
+                              training=case["training"], trace=trace)
+            assert game.length == ref["length"] and game.terminal_value == ref["terminal_value"], name
+            assert len(trace) == len(ref["moves"])
+            for mine, theirs in zip(trace, ref["moves"]):
+                for key in ("action", "root_visits", "root_value_sum", "child_actions", "child_visits",
+                            "child_priors", "child_value_sums"):
+                    assert mine[key] == theirs[key], (name, key)
