@@ -290,6 +290,43 @@ nz_status nz_scs_state_image(nz_scs* h, float* image_dev, void* stream);
 /* status_dev int32[G][7]: player, sub_phase, stage, turn, terminal, terminal_value, length */
 nz_status nz_scs_status(nz_scs* h, int32_t* status_dev, void* stream);
 
+/* ---- MCTS self-play on SCS, lock-step, evaluations supplied by the caller -----
+ * Explorer.run_mcts / Gamer.play_game for G SCS games with the tree, the rules and the
+ * legal-move masks on the device; the network stays outside: nz_scs_search_select hands
+ * out the state images of the leaves that need an evaluation (what Explorer.evaluate
+ * passes to Network_Manager.inference, Explorer.py:145-158) and nz_scs_search_expand
+ * takes (softmax probabilities, value) back (Explorer.py:159-181).  Any PyTorch model
+ * can therefore drive the search (hex or square convs) until the fused kernel covers
+ * SCS boards.  One move for all live games:
+ *   root_children -> host draws gamma noise -> begin_move(noise [G][64])
+ *   repeat: select(images [G][C][R][Cc], leaf_game [G], &n) ; if n == 0 break ;
+ *           evaluate images[0..n) ; expand(probs [n][A], value [n])
+ *   end_move(uniforms [G][3])
+ * nodes_per_game sizes each game's tree arena (nodes are never freed within a game). */
+typedef struct nz_scs_search nz_scs_search;
+nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* desc, const nz_search_cfg* cfg,
+                               int32_t n_games, int32_t nodes_per_game, int32_t device);
+void nz_scs_search_destroy(nz_scs_search* h);
+const char* nz_scs_search_last_error(const nz_scs_search* h);
+nz_status nz_scs_search_reset(nz_scs_search* h, void* stream);
+nz_status nz_scs_search_root_children(nz_scs_search* h, int32_t* n_children_dev, void* stream);
+nz_status nz_scs_search_begin_move(nz_scs_search* h, const double* noise_dev, void* stream);
+/* Synchronises; *n_leaves_host = number of leaves queued (0: every game's search is complete). */
+nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* leaf_game_dev,
+                               int32_t* n_leaves_host, void* stream);
+nz_status nz_scs_search_expand(nz_scs_search* h, const float* probs_dev, const float* value_dev, void* stream);
+nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, void* stream);
+/* status_dev int32[G][7] as nz_scs_status */
+nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream);
+/* Per move m < 256 of game g (dev pointers, any may be NULL): actions int32[G][256] (-1 past the
+ * end), tree_size, n_children int32[G][256], bias, root_value_sum double[G][256]; the root's
+ * children in child order: child_action, child_visit int32[G][256][64], child_prior,
+ * child_value_sum double[G][256][64].  counters_host int64[2]: simulations, expansions. */
+nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
+                               double* bias, double* root_value_sum, int32_t* child_action,
+                               int32_t* child_visit, double* child_prior, double* child_value_sum,
+                               int64_t* counters_host, void* stream);
+
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream
  * (Explorer.py:77-78,89,199,208). */

@@ -95,6 +95,18 @@ SIGNATURES = {
     "nz_scs_legal_mask": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_scs_state_image": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_scs_status": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_create": (c_int32, [POINTER(c_void_p), POINTER(ScsDesc), POINTER(SearchCfg), c_int32, c_int32,
+                                       c_int32]),
+    "nz_scs_search_destroy": (None, [c_void_p]),
+    "nz_scs_search_last_error": (c_char_p, [c_void_p]),
+    "nz_scs_search_reset": (c_int32, [c_void_p, c_void_p]),
+    "nz_scs_search_root_children": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_begin_move": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_select": (c_int32, [c_void_p, c_void_p, c_void_p, POINTER(c_int32), c_void_p]),
+    "nz_scs_search_expand": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_end_move": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_status": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_export": (c_int32, [c_void_p] + [c_void_p] * 9 + [POINTER(c_int64), c_void_p]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

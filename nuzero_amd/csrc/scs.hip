@@ -83,27 +83,16 @@ void neighbours(int rows, int cols, int r, int c, int out[6]) {
 int blocks(int n) { return (n + 127) / 128; }
 }  // namespace
 
-extern "C" {
-
-const char* nz_scs_last_error(const nz_scs* h) { return h ? h->error.c_str() : g_scs_error.c_str(); }
-
-nz_status nz_scs_create(nz_scs** out, const nz_scs_desc* d, int32_t n_games, int32_t device) {
-  if (!out || !d) return scs_fail(nullptr, NZ_ERR_ARG, "null argument");
-  *out = nullptr;
+// nz_scs_desc -> ScsRules (what SCS_Game.load_game_from_config derives, SCS_Game.py:147-240,1570-1779)
+bool nz::scs_fill_rules(const nz_scs_desc* d, ScsRules* out, std::string* err) {
   const int T = d->rows * d->cols;
-  if (d->rows <= 0 || d->cols <= 0 || T > SCS_MAX_TILES) return scs_fail(nullptr, NZ_ERR_ARG, "board larger than %d tiles", SCS_MAX_TILES);
-  if (d->stacking < 1 || d->stacking > SCS_MAX_STACK) return scs_fail(nullptr, NZ_ERR_ARG, "stacking limit must be 1..%d", SCS_MAX_STACK);
-  if (d->n_units < 1 || d->n_units > SCS_MAX_UNITS) return scs_fail(nullptr, NZ_ERR_ARG, "1..%d units supported", SCS_MAX_UNITS);
-  if (d->turns < 1 || d->turns >= SCS_MAX_TURNS) return scs_fail(nullptr, NZ_ERR_ARG, "1..%d turns supported", SCS_MAX_TURNS - 1);
-  if (d->n_vp[0] < 1 || d->n_vp[1] < 1) return scs_fail(nullptr, NZ_ERR_ARG, "each player needs a victory point");
-  if (n_games <= 0) return scs_fail(nullptr, NZ_ERR_ARG, "n_games must be positive");
-  int n_dev = 0;
-  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
-    return scs_fail(nullptr, NZ_ERR_HIP, "no HIP device %d (the SCS operators have no CPU fallback)", device);
-  nz_scs* h = new nz_scs;
-  h->device = device;
-  h->n_games = n_games;
-  ScsRules& r = h->host_rules;
+  auto bad = [&](const char* m) { *err = m; return false; };
+  if (d->rows <= 0 || d->cols <= 0 || T > SCS_MAX_TILES) return bad("board larger than 100 tiles");
+  if (d->stacking < 1 || d->stacking > SCS_MAX_STACK) return bad("stacking limit must be 1..3");
+  if (d->n_units < 1 || d->n_units > SCS_MAX_UNITS) return bad("1..32 units supported");
+  if (d->turns < 1 || d->turns >= SCS_MAX_TURNS) return bad("1..15 turns supported");
+  if (d->n_vp[0] < 1 || d->n_vp[1] < 1) return bad("each player needs a victory point");
+  ScsRules& r = *out;
   memset(&r, 0, sizeof(r));
   const int S = d->stacking;
   r.rows = d->rows; r.cols = d->cols; r.tiles = T; r.turns = d->turns; r.stacking = S; r.n_units = d->n_units;
@@ -137,6 +126,29 @@ nz_status nz_scs_create(nz_scs** out, const nz_scs_desc* d, int32_t n_games, int
     r.u_mov[u] = (int8_t)d->units[u * 5 + 4];
     for (int t = 0; t < T; ++t) r.arrival[u][t] = d->arrival[(size_t)u * T + t];
   }
+  return true;
+}
+
+extern "C" {
+
+const char* nz_scs_last_error(const nz_scs* h) { return h ? h->error.c_str() : g_scs_error.c_str(); }
+
+nz_status nz_scs_create(nz_scs** out, const nz_scs_desc* d, int32_t n_games, int32_t device) {
+  if (!out || !d) return scs_fail(nullptr, NZ_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (n_games <= 0) return scs_fail(nullptr, NZ_ERR_ARG, "n_games must be positive");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+    return scs_fail(nullptr, NZ_ERR_HIP, "no HIP device %d (the SCS operators have no CPU fallback)", device);
+  nz_scs* h = new nz_scs;
+  h->device = device;
+  h->n_games = n_games;
+  std::string err;
+  if (!nz::scs_fill_rules(d, &h->host_rules, &err)) {
+    delete h;
+    return scs_fail(nullptr, NZ_ERR_ARG, "%s", err.c_str());
+  }
+  ScsRules& r = h->host_rules;
   if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&h->rules, sizeof(ScsRules)) != hipSuccess ||
       hipMalloc((void**)&h->states, (size_t)n_games * sizeof(ScsState)) != hipSuccess ||
       hipMemcpy(h->rules, &r, sizeof(r), hipMemcpyHostToDevice) != hipSuccess) {

@@ -16,6 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
+#include "../../include/nuzero_amd.h"
+
 namespace nz {
 
 constexpr int SCS_MAX_TILES = 100;    // 10 x 10
@@ -41,6 +45,8 @@ struct ScsRules {                     // immutable game description (one per eng
       u_mov[SCS_MAX_UNITS];
   uint8_t arrival[SCS_MAX_UNITS][SCS_MAX_TILES];
 };
+
+bool scs_fill_rules(const nz_scs_desc* d, ScsRules* out, std::string* err);   // scs.hip (host)
 
 struct ScsState {
   int16_t stage, turn, length;

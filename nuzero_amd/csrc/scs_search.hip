@@ -1,0 +1,646 @@
+// MCTS over SCS game trees on the device, lock-step, with the leaf evaluations supplied from
+// outside (C ABI nz_scs_search_* / nz_scs_select / nz_scs_expand ...).  One wavefront owns one
+// game: lane j scores child j of the node being left (up to 64 children), lane 0 runs the rules
+// (scs_dev.hpp) on the game's scratch state.
+//
+// Reference semantics (paths relative to the reference repo), as tree_dev.hpp, with the numeric
+// types SCS produces under numpy >= 2 (SURVEY.md section 8a row 3, appendix A rule 11):
+//   * expansion priors are float32: softmax probs (float32) * int8 mask, np.sum in float32
+//     (pairwise), float32 division                                  (Search/Explorer.py:165-179)
+//   * score() with a float32 prior runs in float32: the Python floats u, c and q are cast to
+//     float32 before each operation                                  (Search/Explorer.py:114-130)
+//   * root noise makes the root's children's priors float64 (float32 * (1 - frac) rounded to
+//     float32, plus the float64 noise term); from then on their score is float64
+//                                                                    (Search/Explorer.py:201-210)
+//   * SCS players are 0 and 1, so `parent.to_play == 2` never negates Q (appendix A rule 6)
+// The tree arithmetic must not be contracted: this file is compiled with -ffp-contract=off.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nuzero_amd.h"
+#include "scs_dev.hpp"
+
+using namespace nz;
+
+namespace {
+
+constexpr int MAXC = 64;          // children per node = lanes of a wavefront
+constexpr int MAX_MOVES = 256;    // decisions per game that can be recorded
+constexpr int MAX_ACTIONS = 21 * SCS_MAX_TILES;
+constexpr int MASK_WORDS = (MAX_ACTIONS + 31) / 32;
+
+struct SNode {                    // array-of-structures: one 32-byte record per node
+  double prior;                   // float32 value unless prior_f64
+  double value_sum;
+  int32_t visit;
+  int32_t child_base;
+  uint16_t n_children;
+  uint16_t action;
+  int8_t to_play;                 // -1 until evaluated
+  int8_t prior_f64;               // 1: prior went through the root-noise mix (float64 arithmetic)
+  int8_t terminal;
+  int8_t pad;
+};
+
+struct SearchParams {
+  int32_t n_games, cap, sims, training, softmax_moves, negate_player, tab_len, max_path;
+  double frac, one_minus_frac, value_factor, eps_softmax, eps_random;
+  const double* bias_tab;
+  const double* sqrt_tab;
+  const ScsRules* rules;
+  ScsState* real;          // [G]
+  ScsState* scratch;       // [G]
+  SNode* nodes;            // [G][cap]
+  int32_t* node_count;     // [G]
+  int32_t* root;           // [G]
+  int32_t* sims_left;      // [G]
+  int32_t* pending;        // [G] leaf slot or -1
+  int32_t* path;           // [G][max_path]
+  int32_t* path_len;       // [G]
+  uint32_t* leaf_mask;     // [G][MASK_WORDS] legal actions at the pending leaf
+  int32_t* leaf_count;     // [1]
+  int32_t* error_flag;
+  int64_t* counters;       // [2] simulations, expansions
+  // records [G][MAX_MOVES]...
+  int32_t* rec_action;
+  int32_t* rec_tree_size;
+  int32_t* rec_children;
+  double* rec_bias;
+  double* rec_root_value_sum;
+  int32_t* rec_child_action;   // [G][MAX_MOVES][MAXC]
+  int32_t* rec_child_visit;
+  double* rec_child_prior;
+  double* rec_child_value_sum;
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+template <typename T>
+__device__ __forceinline__ T wave_get(T v, int lane) { return __shfl(v, lane, 64); }
+
+// score of one child (Explorer.score, :114-130) in the reference's dtypes
+__device__ __forceinline__ double child_score(const SearchParams& p, const SNode& c, double sq, double cb, bool negate) {
+  const double u = sq / (double)(c.visit + 1);
+  double q = (c.visit == 0) ? 0.0 : c.value_sum / (double)c.visit;
+  if (negate) q = -q;
+  q = q * p.value_factor;
+  if (c.prior_f64) {
+    double conf = c.prior * u;
+    conf = conf * cb;
+    return conf + q;
+  }
+  float conf = (float)c.prior * (float)u;
+  conf = conf * (float)cb;
+  return (double)(conf + (float)q);
+}
+
+// numpy's float32 pairwise sum of an array that is zero except at the sorted positions idx[0..k)
+// (np.sum over all num_actions entries of `probs`, Explorer.py:169); adding a zero is exact, so
+// only the non-zero entries and the block structure matter
+__device__ float np_sum_sparse_f32(const int* idx, const float* val, int k, int lo, int hi) {
+  const int n = hi - lo;
+  int first = 0;
+  while (first < k && idx[first] < lo) ++first;
+  int last = first;
+  while (last < k && idx[last] < hi) ++last;
+  if (n < 8) {
+    float r = 0.0f;
+    for (int i = first; i < last; ++i) r = r + val[i];
+    return r;
+  }
+  if (n <= 128) {
+    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int body_end = lo + (n - n % 8);
+    int i = first;
+    for (; i < last && idx[i] < body_end; ++i) {
+      const int j = (idx[i] - lo) & 7;
+      r[j] = r[j] + val[i];
+    }
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < last; ++i) res = res + val[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_sum_sparse_f32(idx, val, k, lo, lo + n2) + np_sum_sparse_f32(idx, val, k, lo + n2, hi);
+}
+__device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 here (children of one node)
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r = r + v[i];
+    return r;
+  }
+  double r[8];
+  for (int j = 0; j < 8; ++j) r[j] = v[j];
+  int i = 8;
+  for (; i < n - n % 8; i += 8)
+    for (int j = 0; j < 8; ++j) r[j] = r[j] + v[i + j];
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res = res + v[i];
+  return res;
+}
+
+__global__ void search_reset_kernel(SearchParams p) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g == 0) { *p.leaf_count = 0; *p.error_flag = 0; p.counters[0] = 0; p.counters[1] = 0; }
+  if (g >= p.n_games) return;
+  Scs(*p.rules, p.real[g]).reset();
+  SNode& n = p.nodes[(size_t)g * p.cap];
+  n.prior = 0.0; n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = 0;
+  n.to_play = -1; n.prior_f64 = 0; n.terminal = 0; n.pad = 0;
+  p.node_count[g] = 1;
+  p.root[g] = 0;
+  p.sims_left[g] = 0;
+  p.pending[g] = -1;
+  p.path_len[g] = 0;
+  for (int m = 0; m < MAX_MOVES; ++m) {
+    p.rec_action[g * MAX_MOVES + m] = -1;
+    p.rec_children[g * MAX_MOVES + m] = 0;
+    p.rec_tree_size[g * MAX_MOVES + m] = 0;
+  }
+}
+
+// children of each live game's root (the number of gamma draws of the next move)
+__global__ void root_children_kernel(SearchParams p, int32_t* out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  out[g] = p.real[g].terminal ? 0 : p.nodes[(size_t)g * p.cap + p.root[g]].n_children;
+}
+
+// add_exploration_noise (Explorer.py:201-210) and the start of a move's search
+__global__ void begin_move_kernel(SearchParams p, const double* __restrict__ noise) {
+  const int g = blockIdx.x;
+  const int lane = lane_id();
+  if (p.real[g].terminal) return;
+  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  const SNode& root = nodes[p.root[g]];
+  if (p.training && lane < root.n_children) {
+    SNode& c = nodes[root.child_base + lane];
+    const double n = noise[(size_t)g * MAXC + lane];
+    double a;
+    if (c.prior_f64) a = c.prior * p.one_minus_frac;
+    else a = (double)((float)c.prior * (float)p.one_minus_frac);
+    const double b = n * p.frac;
+    c.prior = a + b;
+    c.prior_f64 = 1;
+  }
+  if (lane == 0) {
+    p.sims_left[g] = p.sims;
+    p.pending[g] = -1;
+  }
+}
+
+// Simulate until the game waits on a leaf that needs an evaluation, or its simulations are used up
+// (Explorer.run_mcts, :49-61).  One wavefront per game.
+__global__ __launch_bounds__(64) void select_kernel(SearchParams p, float* __restrict__ images,
+                                                     int32_t* __restrict__ leaf_game) {
+  const int g = blockIdx.x;
+  const int lane = lane_id();
+  if (p.real[g].terminal || p.pending[g] >= 0) return;
+  const ScsRules& R = *p.rules;
+  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  int32_t* path = p.path + (size_t)g * p.max_path;
+  ScsState& sc = p.scratch[g];
+  int sims_left = p.sims_left[g];
+  const int root = p.root[g];
+  long n_sim = 0;
+
+  while (sims_left > 0) {
+    // scratch_game = game.shallow_clone()
+    {
+      const int words = (int)(sizeof(ScsState) / 4);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&p.real[g]);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&sc);
+      for (int i = lane; i < words; i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    int node = root, plen = 1;
+    if (lane == 0) path[0] = root;
+    while (nodes[node].n_children > 0) {
+      const SNode parent = nodes[node];
+      if (parent.visit >= p.tab_len || plen >= p.max_path) {
+        if (lane == 0) atomicOr(p.error_flag, 2);
+        sims_left = 0;
+        break;
+      }
+      const double sq = p.sqrt_tab[parent.visit], cb = p.bias_tab[parent.visit];
+      const bool negate = parent.to_play == p.negate_player;
+      double score = -INFINITY;
+      int key = -1;
+      if (lane < parent.n_children) {
+        const SNode c = nodes[parent.child_base + lane];
+        score = child_score(p, c, sq, cb, negate);
+        key = ((int)c.action << 8) | lane;
+      }
+      // max over (score, action): the larger action wins a tie (Explorer.py:100)
+      for (int w = 32; w >= 1; w >>= 1) {
+        const double os = __shfl_xor(score, w, 64);
+        const int ok = __shfl_xor(key, w, 64);
+        if (os > score || (os == score && ok > key)) { score = os; key = ok; }
+      }
+      node = parent.child_base + (key & 0xff);
+      if (lane == 0) {
+        Scs(R, sc).step(key >> 8);
+        path[plen] = node;
+      }
+      ++plen;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (sims_left == 0) break;
+    // evaluate (Explorer.py:137-181)
+    const int to_play = sc.player, term = sc.terminal;
+    if (term) {
+      if (lane == 0) {
+        nodes[node].to_play = (int8_t)to_play;
+        nodes[node].terminal = 1;
+      }
+      const double value = (double)sc.terminal_value;
+      for (int i = lane; i < plen; i += 64) {
+        SNode& n = nodes[path[i]];
+        n.visit += 1;
+        n.value_sum = n.value_sum + value;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      --sims_left;
+      ++n_sim;
+      continue;
+    }
+    // leaf needs an evaluation: queue its state image and remember its legal actions
+    int slot = 0;
+    if (lane == 0) {
+      slot = atomicAdd(p.leaf_count, 1);
+      leaf_game[slot] = g;
+      p.pending[g] = slot;
+      p.path_len[g] = plen;
+      nodes[node].to_play = (int8_t)to_play;
+      uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
+      for (int i = 0; i < MASK_WORDS; ++i) m[i] = 0u;
+      Scs(R, sc).for_each_legal([&](int a) { m[a >> 5] |= 1u << (a & 31); });
+      Scs(R, sc).state_image(images + (size_t)slot * R.channels * R.tiles);
+    }
+    break;
+  }
+  if (lane == 0) {
+    p.sims_left[g] = sims_left;
+    if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)n_sim);
+  }
+}
+
+// Finish the pending expansions with the supplied evaluations (Explorer.py:162-181) and back up.
+// probs: [n_leaves][num_actions] float32 post-softmax, value: [n_leaves] float32.
+__global__ __launch_bounds__(64) void expand_kernel(SearchParams p, const float* __restrict__ probs,
+                                                     const float* __restrict__ value) {
+  const int g = blockIdx.x;
+  const int lane = lane_id();
+  const int slot = p.pending[g];
+  if (slot < 0) return;
+  const ScsRules& R = *p.rules;
+  const int A = R.planes * R.tiles;
+  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  const int32_t* path = p.path + (size_t)g * p.max_path;
+  const int plen = p.path_len[g];
+  const int leaf = path[plen - 1];
+  if (lane == 0) {
+    // legal actions ascending
+    int idx[MAXC];
+    float val[MAXC];
+    int k = 0;
+    bool overflow = false;
+    const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
+    for (int w = 0; w < MASK_WORDS; ++w) {
+      uint32_t bits = m[w];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (k < MAXC) { idx[k] = w * 32 + b; val[k] = probs[(size_t)slot * A + idx[k]]; ++k; }
+        else overflow = true;
+      }
+    }
+    const int base = p.node_count[g];
+    if (overflow || base + k > p.cap) {
+      atomicOr(p.error_flag, overflow ? 16 : 1);
+    } else {
+      float total = np_sum_sparse_f32(idx, val, k, 0, A);
+      if (total == 0.0f) {              // probs += mask
+        for (int i = 0; i < k; ++i) val[i] = val[i] + 1.0f;
+        total = np_sum_sparse_f32(idx, val, k, 0, A);
+      }
+      for (int i = 0; i < k; ++i) {
+        SNode& c = nodes[base + i];
+        c.prior = (double)(val[i] / total);
+        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)idx[i];
+        c.to_play = -1; c.prior_f64 = 0; c.terminal = 0; c.pad = 0;
+      }
+      nodes[leaf].child_base = base;
+      nodes[leaf].n_children = (uint16_t)k;
+      p.node_count[g] = base + k;
+    }
+    p.pending[g] = -1;
+    p.sims_left[g] -= 1;
+    atomicAdd((unsigned long long*)&p.counters[0], 1ull);
+    atomicAdd((unsigned long long*)&p.counters[1], 1ull);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const double v = (double)value[slot];
+  for (int i = lane; i < plen; i += 64) {
+    SNode& n = nodes[path[i]];
+    n.visit += 1;
+    n.value_sum = n.value_sum + v;
+  }
+}
+
+// select_action, records, step and re-rooting (Explorer.py:70-97,183-199; Gamer.py:71-79)
+__global__ void end_move_kernel(SearchParams p, const double* __restrict__ uniforms) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  ScsState& real = p.real[g];
+  if (real.terminal) return;
+  const ScsRules& R = *p.rules;
+  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  const SNode root = nodes[p.root[g]];
+  const int k = root.n_children, move = real.length;
+  if (k == 0 || p.sims_left[g] != 0 || p.pending[g] >= 0 || move >= MAX_MOVES) {
+    atomicOr(p.error_flag, move >= MAX_MOVES ? 32 : 4);
+    return;
+  }
+  const size_t gm = (size_t)g * MAX_MOVES + move;
+  int best = 0;
+  for (int j = 0; j < k; ++j) {
+    const SNode& c = nodes[root.child_base + j];
+    p.rec_child_action[gm * MAXC + j] = c.action;
+    p.rec_child_visit[gm * MAXC + j] = c.visit;
+    p.rec_child_prior[gm * MAXC + j] = c.prior;
+    p.rec_child_value_sum[gm * MAXC + j] = c.value_sum;
+    if (c.visit > nodes[root.child_base + best].visit) best = j;      // max_action: first maximum
+  }
+  p.rec_tree_size[gm] = root.visit;
+  p.rec_children[gm] = k;
+  p.rec_bias[gm] = root.visit < p.tab_len ? p.bias_tab[root.visit] : 0.0;
+  p.rec_root_value_sum[gm] = root.value_sum;
+
+  int mode = 0;
+  double u3 = 0.0;
+  if (p.training) {
+    const double u1 = uniforms[g * 3], u2 = uniforms[g * 3 + 1];
+    u3 = uniforms[g * 3 + 2];
+    if (move < p.softmax_moves) mode = 1;
+    else if (u1 < p.eps_softmax) mode = 1;
+    else if (u2 < p.eps_random) mode = 2;
+  }
+  int chosen_child = best;
+  if (mode == 1) {                         // softmax_action (Explorer.py:187-199)
+    double e[MAXC];
+    int mx = 0;
+    for (int j = 0; j < k; ++j) mx = max(mx, nodes[root.child_base + j].visit);
+    for (int j = 0; j < k; ++j) e[j] = exp((double)(nodes[root.child_base + j].visit - mx));
+    const double s = np_sum_f64(e, k);
+    for (int j = 0; j < k; ++j) e[j] = e[j] / s;
+    const double s2 = np_sum_f64(e, k);
+    double run = 0.0, last;
+    for (int j = 0; j < k; ++j) { e[j] = e[j] / s2; }
+    for (int j = 0; j < k; ++j) { run = j == 0 ? e[0] : run + e[j]; e[j] = run; }
+    last = e[k - 1];
+    chosen_child = k - 1;
+    for (int j = 0; j < k; ++j) if (e[j] / last > u3) { chosen_child = j; break; }
+  } else if (mode == 2) {                  // uniform over the legal actions (Explorer.py:86-89)
+    // p = mask / n_valid over all actions; cdf = cumsum(p) / cdf[-1]; searchsorted(u, 'right').
+    // The root's children are exactly the legal actions, in ascending order.
+    const double pv = 1.0 / (double)k;     // 1 / np.sum(mask): int8 sum -> exact integer
+    double run = 0.0;
+    double cdf[MAXC];
+    for (int j = 0; j < k; ++j) { run = j == 0 ? pv : run + pv; cdf[j] = run; }
+    chosen_child = k - 1;
+    for (int j = 0; j < k; ++j) if (cdf[j] / cdf[k - 1] > u3) { chosen_child = j; break; }
+  }
+  const int action = nodes[root.child_base + chosen_child].action;
+  p.rec_action[gm] = action;
+  Scs(R, real).step(action);
+  p.root[g] = root.child_base + chosen_child;
+}
+
+}  // namespace
+
+struct nz_scs_search {
+  int device = 0, n_games = 0;
+  nz_search_cfg cfg;
+  ScsRules host_rules;
+  SearchParams p;
+  std::vector<void*> allocs;
+  std::string error;
+};
+
+namespace {
+thread_local std::string g_err;
+nz_status sfail(nz_scs_search* h, nz_status code, const char* fmt, ...) {
+  char buf[384];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->error = buf; else g_err = buf;
+  return code;
+}
+#define S_HIP(h, call)                                                                            \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) return sfail((h), NZ_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+template <typename T>
+bool dalloc(nz_scs_search* h, T** out, size_t n) {
+  void* q = nullptr;
+  if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) return false;
+  h->allocs.push_back(q);
+  *out = static_cast<T*>(q);
+  return true;
+}
+nz_status check_flag(nz_scs_search* h, hipStream_t s) {
+  int32_t f = 0;
+  S_HIP(h, hipMemcpyAsync(&f, h->p.error_flag, sizeof(f), hipMemcpyDeviceToHost, s));
+  S_HIP(h, hipStreamSynchronize(s));
+  if (f) return sfail(h, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 arena full, 2 visit table/path too short, "
+                                          "4 move ended before its search, 16 more than 64 legal actions, 32 game too long)", f);
+  return NZ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* nz_scs_search_last_error(const nz_scs_search* h) { return h ? h->error.c_str() : g_err.c_str(); }
+
+nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const nz_search_cfg* cfg, int32_t n_games,
+                               int32_t nodes_per_game, int32_t device) {
+  if (!out || !d || !cfg) return sfail(nullptr, NZ_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (n_games <= 0 || cfg->mcts_simulations <= 0 || nodes_per_game < 2) return sfail(nullptr, NZ_ERR_ARG, "bad sizes");
+  if (!cfg->keep_subtree) return sfail(nullptr, NZ_ERR_ARG, "keep_subtree = False is not supported (Gamer.py:78-79)");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+    return sfail(nullptr, NZ_ERR_HIP, "no HIP device %d (no CPU fallback)", device);
+  nz_scs_search* h = new nz_scs_search;
+  h->device = device;
+  h->n_games = n_games;
+  h->cfg = *cfg;
+  std::string err;
+  if (!scs_fill_rules(d, &h->host_rules, &err)) { delete h; return sfail(nullptr, NZ_ERR_ARG, "%s", err.c_str()); }
+  if (h->host_rules.planes * h->host_rules.tiles > MAX_ACTIONS) { delete h; return sfail(nullptr, NZ_ERR_ARG, "too many actions"); }
+  (void)hipSetDevice(device);
+  SearchParams& p = h->p;
+  memset(&p, 0, sizeof(p));
+  const size_t G = n_games;
+  p.n_games = n_games;
+  p.cap = nodes_per_game;
+  p.sims = cfg->mcts_simulations;
+  p.training = cfg->training;
+  p.softmax_moves = cfg->number_of_softmax_moves;
+  p.negate_player = 2;                       // Explorer.py:124; SCS players are 0 and 1
+  p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
+  p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
+  p.frac = cfg->root_exploration_fraction;
+  p.one_minus_frac = 1.0 - cfg->root_exploration_fraction;
+  p.value_factor = cfg->value_factor;
+  p.eps_softmax = cfg->epsilon_softmax_exploration;
+  p.eps_random = cfg->epsilon_random_exploration;
+  ScsRules* rules = nullptr;
+  double *bias = nullptr, *sq = nullptr;
+  const size_t GM = G * MAX_MOVES;
+  bool ok = dalloc(h, &rules, 1) && dalloc(h, &p.real, G) && dalloc(h, &p.scratch, G) &&
+            dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
+            dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
+            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 1) &&
+            dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 2) && dalloc(h, &bias, (size_t)p.tab_len) &&
+            dalloc(h, &sq, (size_t)p.tab_len) && dalloc(h, &p.rec_action, GM) && dalloc(h, &p.rec_tree_size, GM) &&
+            dalloc(h, &p.rec_children, GM) && dalloc(h, &p.rec_bias, GM) && dalloc(h, &p.rec_root_value_sum, GM) &&
+            dalloc(h, &p.rec_child_action, GM * MAXC) && dalloc(h, &p.rec_child_visit, GM * MAXC) &&
+            dalloc(h, &p.rec_child_prior, GM * MAXC) && dalloc(h, &p.rec_child_value_sum, GM * MAXC);
+  if (!ok) { nz_scs_search_destroy(h); return sfail(nullptr, NZ_ERR_HIP, "device allocation failed"); }
+  std::vector<double> hb(p.tab_len), hs(p.tab_len);
+  for (int n = 0; n < p.tab_len; ++n) {      // Explorer.py:103-112 with the host libm
+    hb[n] = std::log(((double)n + cfg->pb_c_base + 1.0) / cfg->pb_c_base) + cfg->pb_c_init;
+    hs[n] = std::sqrt((double)n);
+  }
+  if (hipMemcpy(rules, &h->host_rules, sizeof(ScsRules), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(bias, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(sq, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+    nz_scs_search_destroy(h);
+    return sfail(nullptr, NZ_ERR_HIP, "upload failed");
+  }
+  p.rules = rules;
+  p.bias_tab = bias;
+  p.sqrt_tab = sq;
+  hipLaunchKernelGGL(search_reset_kernel, dim3((n_games + 127) / 128), dim3(128), 0, nullptr, p);
+  if (hipDeviceSynchronize() != hipSuccess) { nz_scs_search_destroy(h); return sfail(nullptr, NZ_ERR_HIP, "reset failed"); }
+  *out = h;
+  return NZ_OK;
+}
+
+void nz_scs_search_destroy(nz_scs_search* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* q : h->allocs) (void)hipFree(q);
+  delete h;
+}
+
+nz_status nz_scs_search_reset(nz_scs_search* h, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(search_reset_kernel, dim3((h->n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream, h->p);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_scs_search_root_children(nz_scs_search* h, int32_t* out_dev, void* stream) {
+  if (!h || !out_dev) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(root_children_kernel, dim3((h->n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream, h->p, out_dev);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_scs_search_begin_move(nz_scs_search* h, const double* noise_dev, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  if (h->cfg.training && !noise_dev) return sfail(h, NZ_ERR_ARG, "training search needs noise");
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(begin_move_kernel, dim3(h->n_games), dim3(64), 0, (hipStream_t)stream, h->p, noise_dev);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* leaf_game_dev, int32_t* n_leaves_host,
+                               void* stream) {
+  if (!h || !images_dev || !leaf_game_dev || !n_leaves_host) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(select_kernel, dim3(h->n_games), dim3(64), 0, s, h->p, images_dev, leaf_game_dev);
+  S_HIP(h, hipGetLastError());
+  S_HIP(h, hipMemcpyAsync(n_leaves_host, h->p.leaf_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  S_HIP(h, hipStreamSynchronize(s));
+  return check_flag(h, s);
+}
+
+nz_status nz_scs_search_expand(nz_scs_search* h, const float* probs_dev, const float* value_dev, void* stream) {
+  if (!h || !probs_dev || !value_dev) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(expand_kernel, dim3(h->n_games), dim3(64), 0, (hipStream_t)stream, h->p, probs_dev, value_dev);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
+}
+
+nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  if (h->cfg.training && !uniforms_dev) return sfail(h, NZ_ERR_ARG, "training search needs uniforms");
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(end_move_kernel, dim3((h->n_games + 63) / 64), dim3(64), 0, s, h->p, uniforms_dev);
+  S_HIP(h, hipGetLastError());
+  return check_flag(h, s);
+}
+
+nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream);
+
+nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
+                               double* bias, double* root_value_sum, int32_t* child_action, int32_t* child_visit,
+                               double* child_prior, double* child_value_sum, int64_t* counters_host, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t GM = (size_t)h->n_games * MAX_MOVES;
+  const SearchParams& p = h->p;
+#define CP(dst, src, n)                                                                          \
+  if (dst) S_HIP(h, hipMemcpyAsync(dst, src, (n) * sizeof(*src), hipMemcpyDeviceToDevice, s))
+  CP(actions, p.rec_action, GM); CP(tree_size, p.rec_tree_size, GM); CP(n_children, p.rec_children, GM);
+  CP(bias, p.rec_bias, GM); CP(root_value_sum, p.rec_root_value_sum, GM);
+  CP(child_action, p.rec_child_action, GM * MAXC); CP(child_visit, p.rec_child_visit, GM * MAXC);
+  CP(child_prior, p.rec_child_prior, GM * MAXC); CP(child_value_sum, p.rec_child_value_sum, GM * MAXC);
+#undef CP
+  if (counters_host) {
+    S_HIP(h, hipMemcpyAsync(counters_host, p.counters, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    S_HIP(h, hipStreamSynchronize(s));
+  }
+  return NZ_OK;
+}
+
+}  // extern "C"
+
+namespace {
+__global__ void search_status_kernel(SearchParams p, int32_t* out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  const ScsState& s = p.real[g];
+  int32_t* o = out + g * 7;
+  o[0] = s.player; o[1] = s.sub_phase; o[2] = s.stage; o[3] = s.turn; o[4] = s.terminal; o[5] = s.terminal_value;
+  o[6] = s.length;
+}
+}  // namespace
+
+extern "C" nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream) {
+  if (!h || !status_dev) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(search_status_kernel, dim3((h->n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream, h->p, status_dev);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
+}

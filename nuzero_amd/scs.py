@@ -134,3 +134,132 @@ class ScsBatch:
         s = torch.empty((self.n_games, 7), dtype=torch.int32, device=self.device)
         self._check(lib.nz_scs_status(self._h, c_void_p(s.data_ptr()), self._stream()))
         return s
+
+
+class ScsSelfPlay:
+    """MCTS self-play on SCS with the tree, rules and masks on the device and the leaf evaluations
+    supplied by `evaluator(images) -> (probs [n, A] float32 post-softmax, values [n] float32)`
+    (device tensors in, device or host tensors out) -- e.g. a PyTorch model followed by softmax.
+    Lock-step: one host round trip per simulation wave (C ABI nz_scs_search_*)."""
+
+    MAX_MOVES, MAX_CHILDREN = 256, 64
+
+    def __init__(self, config, search_config, n_games, training=True, device=0, nodes_per_game=None):
+        from .search_config import to_struct
+        if not torch.cuda.is_available():
+            raise RuntimeError("nuzero_amd needs a ROCm GPU; there is no CPU fallback")
+        self.cfg = config if isinstance(config, ScsGameConfig) else ScsGameConfig(config)
+        c = self.cfg
+        self.search_config, self.training = search_config, bool(training)
+        self.device = torch.device("cuda", device)
+        self.n_games = n_games
+        sims = int(search_config["Simulation"]["mcts_simulations"])
+        if nodes_per_game is None:      # nodes are never freed within a game: 40 children x sims x decisions
+            nodes_per_game = 1 + sims * 40 * 160
+        self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
+                      np.ascontiguousarray(c.arrival))
+        d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
+                         terrain=self._keep[0].ctypes.data, n_vp=(c_int32 * 2)(*c.n_vp), vp=self._keep[1].ctypes.data,
+                         n_units=len(c.units), units=self._keep[2].ctypes.data, arrival=self._keep[3].ctypes.data)
+        sc = to_struct(search_config, training)
+        self._h = c_void_p(0)
+        st = lib.nz_scs_search_create(byref(self._h), byref(d), byref(sc), int(n_games), int(nodes_per_game),
+                                      int(device))
+        if st != _lib.NZ_OK:
+            raise _lib.NzError(st, (lib.nz_scs_search_last_error(None) or b"").decode())
+        G = n_games
+        self._images = torch.empty((G, c.channels, c.rows, c.cols), dtype=torch.float32, device=self.device)
+        self._leaf_game = torch.empty((G,), dtype=torch.int32, device=self.device)
+        self.evaluations = 0
+
+    def _check(self, st):
+        if st != _lib.NZ_OK:
+            raise _lib.NzError(st, (lib.nz_scs_search_last_error(self._h) or b"").decode())
+
+    def _stream(self):
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if self._h.value:
+            lib.nz_scs_search_destroy(self._h)
+            self._h = c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self):
+        s = torch.empty((self.n_games, 7), dtype=torch.int32, device=self.device)
+        self._check(lib.nz_scs_search_status(self._h, c_void_p(s.data_ptr()), self._stream()))
+        return s.cpu().numpy()
+
+    def play(self, evaluator, seeds):
+        """Reset and play every game to the end; game g draws from RandomState(seeds[g]) in the
+        reference's order (gamma x n_root_children, two uniforms, at most one more for choice)."""
+        ex = self.search_config["Exploration"]
+        G, A = self.n_games, self.cfg.num_actions
+        rngs = [np.random.RandomState(int(s)) for s in seeds]
+        self._check(lib.nz_scs_search_reset(self._h, self._stream()))
+        nchild_dev = torch.empty((G,), dtype=torch.int32, device=self.device)
+        for _ in range(self.MAX_MOVES):
+            st = self.status()
+            alive = st[:, 4] == 0
+            if not alive.any():
+                break
+            noise = np.zeros((G, self.MAX_CHILDREN), np.float64)
+            uni = np.zeros((G, 3), np.float64)
+            if self.training:
+                self._check(lib.nz_scs_search_root_children(self._h, c_void_p(nchild_dev.data_ptr()), self._stream()))
+                nchild = nchild_dev.cpu().numpy()
+                for g in np.nonzero(alive)[0]:
+                    rs, n = rngs[g], int(nchild[g])
+                    noise[g, :n] = rs.gamma(ex["root_dist_alpha"], ex["root_dist_beta"], n)
+                    if st[g, 6] < ex["number_of_softmax_moves"]:
+                        uni[g, 2] = rs.random_sample()
+                    else:
+                        u1, u2 = rs.random_sample(), rs.random_sample()
+                        uni[g, 0], uni[g, 1] = u1, u2
+                        if u1 < ex["epsilon_softmax_exploration"] or u2 < ex["epsilon_random_exploration"]:
+                            uni[g, 2] = rs.random_sample()
+            noise_d = torch.from_numpy(noise).to(self.device)
+            uni_d = torch.from_numpy(uni).to(self.device)
+            self._check(lib.nz_scs_search_begin_move(self._h, c_void_p(noise_d.data_ptr()), self._stream()))
+            while True:
+                n = c_int32(0)
+                self._check(lib.nz_scs_search_select(self._h, c_void_p(self._images.data_ptr()),
+                                                     c_void_p(self._leaf_game.data_ptr()), byref(n), self._stream()))
+                if n.value == 0:
+                    break
+                probs, values = evaluator(self._images[:n.value])
+                probs = torch.as_tensor(probs, dtype=torch.float32).to(self.device).contiguous()
+                values = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous()
+                assert probs.shape == (n.value, A) and values.shape == (n.value,)
+                self.evaluations += n.value
+                self._check(lib.nz_scs_search_expand(self._h, c_void_p(probs.data_ptr()), c_void_p(values.data_ptr()),
+                                                     self._stream()))
+            self._check(lib.nz_scs_search_end_move(self._h, c_void_p(uni_d.data_ptr()), self._stream()))
+        return self.export()
+
+    def export(self):
+        G, M, C = self.n_games, self.MAX_MOVES, self.MAX_CHILDREN
+        dev = self.device
+        t = {"actions": torch.empty((G, M), dtype=torch.int32, device=dev),
+             "tree_size": torch.empty((G, M), dtype=torch.int32, device=dev),
+             "n_children": torch.empty((G, M), dtype=torch.int32, device=dev),
+             "bias": torch.empty((G, M), dtype=torch.float64, device=dev),
+             "root_value_sum": torch.empty((G, M), dtype=torch.float64, device=dev),
+             "child_action": torch.empty((G, M, C), dtype=torch.int32, device=dev),
+             "child_visit": torch.empty((G, M, C), dtype=torch.int32, device=dev),
+             "child_prior": torch.empty((G, M, C), dtype=torch.float64, device=dev),
+             "child_value_sum": torch.empty((G, M, C), dtype=torch.float64, device=dev)}
+        counters = (ctypes.c_int64 * 2)()
+        self._check(lib.nz_scs_search_export(self._h, *[c_void_p(t[k].data_ptr()) for k in (
+            "actions", "tree_size", "n_children", "bias", "root_value_sum", "child_action", "child_visit",
+            "child_prior", "child_value_sum")], counters, self._stream()))
+        out = {k: v.cpu().numpy() for k, v in t.items()}
+        st = self.status()
+        out["lengths"], out["outcomes"] = st[:, 6].copy(), st[:, 5].copy()
+        out["simulations"], out["expansions"] = int(counters[0]), int(counters[1])
+        return out

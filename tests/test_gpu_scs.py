@@ -47,3 +47,47 @@ def test_scs_device_rules_equal_oracle(name, n_games):
     outcomes = [g.terminal_value for g in games]
     assert len(outcomes) == n_games
     batch.close()
+
+
+def _host_evaluator(num_actions):
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scs_eval import evaluate_image
+
+    def ev(images):
+        imgs = images.cpu().numpy()
+        out = [evaluate_image(im, num_actions) for im in imgs]
+        return (torch.from_numpy(np.stack([o[0] for o in out])), torch.from_numpy(np.array([o[1] for o in out], np.float32)))
+    return ev
+
+
+def test_scs_device_search_equals_reference():
+    """MCTS self-play on SCS with tree + rules on the device and evaluations injected from the host:
+    every root statistic of every move must equal the games the genuine reference played
+    (tests/golden/make_golden_scs_search.py): float32 priors, float64 after noise, exploration moves."""
+    import gzip
+    import json
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    with gzip.open(os.path.join(GOLDEN, "scs_search_kat.json.gz"), "rt") as f:
+        kat = json.load(f)
+    files = {"mirrored_config_5.yml": "mirrored_5x5.yml"}
+    for name, case in kat.items():
+        cfg = ScsGameConfig(os.path.join(GOLDEN, "scs_configs", files.get(case["config_file"], case["config_file"])))
+        games = case["games"]
+        sp = ScsSelfPlay(cfg, case["config"], len(games), training=case["training"])
+        r = sp.play(_host_evaluator(cfg.num_actions), [g["seed"] for g in games])
+        for g, ref in enumerate(games):
+            assert r["lengths"][g] == ref["length"] and r["outcomes"][g] == ref["terminal_value"], (name, g)
+            for m, mv in enumerate(ref["moves"]):
+                k = len(mv["child_actions"])
+                assert r["actions"][g, m] == mv["action"], (name, g, m)
+                assert r["tree_size"][g, m] == mv["root_visits"] and r["n_children"][g, m] == k
+                assert r["bias"][g, m] == mv["bias"] and r["root_value_sum"][g, m] == mv["root_value_sum"]
+                assert r["child_action"][g, m, :k].tolist() == mv["child_actions"]
+                assert r["child_visit"][g, m, :k].tolist() == mv["child_visits"], (name, g, m)
+                assert r["child_prior"][g, m, :k].tolist() == mv["child_priors"], (name, g, m)
+                assert r["child_value_sum"][g, m, :k].tolist() == mv["child_value_sums"]
+            assert (r["actions"][g, ref["length"]:] == -1).all()
+        assert r["expansions"] == sum(g["evaluations"] for g in games)
+        sp.close()
