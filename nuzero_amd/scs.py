@@ -263,3 +263,62 @@ class ScsSelfPlay:
         out["lengths"], out["outcomes"] = st[:, 6].copy(), st[:, 5].copy()
         out["simulations"], out["expansions"] = int(counters[0]), int(counters[1])
         return out
+
+
+def torch_evaluator(model, recurrent_iterations=2):
+    """Evaluator for ScsSelfPlay from a PyTorch policy/value module with the reference's calling
+    convention (Network_Manager.inference, Neural_Networks/Network_Manager.py:46-64): recurrent
+    models are called as model(x, iters) -> ((policy, value), thought), others as model(x) ->
+    (policy, value).  Softmax over ALL logits (Explorer.py:159) is applied here, on the GPU."""
+    model.eval()
+    recurrent = bool(getattr(model, "recurrent", False))
+
+    def ev(images):
+        with torch.no_grad():
+            if recurrent:
+                (p, v), _ = model(images, recurrent_iterations)
+            else:
+                p, v = model(images)
+        probs = torch.softmax(p.reshape(p.shape[0], -1).float(), dim=1)
+        return probs, v.reshape(-1).float()
+    return ev
+
+
+class ScsGameRecord:
+    """A finished SCS game as ReplayBuffer.save_game and the trainer read it
+    (Training/ReplayBuffer.py:31-33, SCS_Game.py:1517-1528)."""
+
+    def __init__(self, states, child_actions, child_visits, n_children, length, terminal_value, num_actions):
+        self.length, self.terminal_value = int(length), int(terminal_value)
+        self.state_history = [torch.from_numpy(np.ascontiguousarray(states[m:m + 1])) for m in range(self.length)]
+        self.child_policy = []
+        for m in range(self.length):
+            k = int(n_children[m])
+            visits = [int(v) for v in child_visits[m, :k]]
+            total = sum(visits)
+            pol = [0] * num_actions
+            for a, v in zip(child_actions[m, :k], visits):
+                pol[int(a)] = v / total
+            self.child_policy.append(pol)
+
+    def get_state_from_history(self, i):
+        return self.state_history[i]
+
+    def make_target(self, i):
+        return (self.terminal_value, self.child_policy[i])
+
+
+def scs_game_records(selfplay, result):
+    """GameRecords of a finished ScsSelfPlay round.  The per-move state images are regenerated by
+    replaying the recorded actions through the device rules (ScsBatch), one image per decision."""
+    cfg, G = selfplay.cfg, selfplay.n_games
+    lengths = result["lengths"]
+    batch = ScsBatch(cfg, G, device=selfplay.device.index or 0)
+    L = int(lengths.max())
+    states = np.zeros((G, L, cfg.channels, cfg.rows, cfg.cols), np.float32)
+    for m in range(L):
+        states[:, m] = batch.state_image().cpu().numpy()
+        batch.step(np.where(m < lengths, result["actions"][:, m], -1).astype(np.int32))
+    batch.close()
+    return [ScsGameRecord(states[g], result["child_action"][g], result["child_visit"][g], result["n_children"][g],
+                          lengths[g], result["outcomes"][g], cfg.num_actions) for g in range(G)]

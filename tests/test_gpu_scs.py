@@ -91,3 +91,63 @@ def test_scs_device_search_equals_reference():
             assert (r["actions"][g, ref["length"]:] == -1).all()
         assert r["expansions"] == sum(g["evaluations"] for g in games)
         sp.close()
+
+
+def test_scs_selfplay_with_a_torch_network_and_records():
+    """End to end on SCS: a PyTorch conv net (square 3x3 convs, the hex=False form of the reference's
+    nets) evaluates the leaves on the GPU, tree/rules/masks run on the device; the finished games
+    come back as replay-buffer records whose targets follow SCS_Game.store_search_statistics."""
+    import torch
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig, torch_evaluator, scs_game_records
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    from oracle.scs import ScsConfig, ScsGame
+    path = os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsGameConfig(path)
+
+    class TinyNet(torch.nn.Module):
+        recurrent = False
+
+        def __init__(self, cin, planes):
+            super().__init__()
+            self.trunk = torch.nn.Sequential(torch.nn.Conv2d(cin, 16, 3, padding="same", bias=False), torch.nn.ReLU(),
+                                             torch.nn.Conv2d(16, 16, 3, padding="same", bias=False), torch.nn.ReLU())
+            self.policy = torch.nn.Conv2d(16, planes, 3, padding="same", bias=False)
+            self.value = torch.nn.Conv2d(16, 1, 3, padding="same", bias=False)
+
+        def forward(self, x):
+            t = self.trunk(x)
+            return self.policy(t), torch.tanh(self.value(t).mean(dim=(1, 2, 3))).reshape(-1, 1)
+
+    torch.manual_seed(0)
+    net = TinyNet(cfg.channels, cfg.planes).cuda()
+    search = {"Simulation": {"mcts_simulations": 12, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.2, "root_dist_beta": 1}}
+    sp = ScsSelfPlay(cfg, search, 6)
+    r = sp.play(torch_evaluator(net), seeds=range(100, 106))
+    assert (r["lengths"] > 10).all() and r["expansions"] == sp.evaluations
+    # every recorded action must be legal when replayed through the oracle, and end where the device did
+    ocfg = ScsConfig(path)
+    for g in range(6):
+        og = ScsGame(ocfg)
+        for m in range(r["lengths"][g]):
+            a = int(r["actions"][g, m])
+            legal = np.nonzero(og.possible_actions().reshape(-1))[0]
+            k = r["n_children"][g, m]
+            assert r["child_action"][g, m, :k].tolist() == legal.tolist()
+            assert r["child_visit"][g, m, :k].sum() == r["tree_size"][g, m] - 1
+            og.step_index(a)
+        assert og.terminal and og.terminal_value == r["outcomes"][g]
+    recs = scs_game_records(sp, r)
+    rb = ReplayBuffer(100, 8)
+    for rec in recs:
+        rb.save_game(rec, 0)
+    assert rb.len() == int(r["lengths"].sum())
+    state, (value, policy), idx = rb.get_buffer()[0]
+    assert tuple(state.shape) == (1, cfg.channels, cfg.rows, cfg.cols) and len(policy) == cfg.num_actions
+    assert abs(sum(policy) - 1.0) < 1e-12 and value in (-1, 0, 1)
+    og = ScsGame(ocfg)
+    assert np.array_equal(recs[0].get_state_from_history(0).numpy(), og.state_image())
+    sp.close()
