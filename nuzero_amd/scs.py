@@ -265,22 +265,27 @@ class ScsSelfPlay:
         return out
 
 
-def torch_evaluator(model, recurrent_iterations=2):
+def torch_evaluator(model, recurrent_iterations=2, pad_to=None):
     """Evaluator for ScsSelfPlay from a PyTorch policy/value module with the reference's calling
     convention (Network_Manager.inference, Neural_Networks/Network_Manager.py:46-64): recurrent
     models are called as model(x, iters) -> ((policy, value), thought), others as model(x) ->
-    (policy, value).  Softmax over ALL logits (Explorer.py:159) is applied here, on the GPU."""
+    (policy, value).  Softmax over ALL logits (Explorer.py:159) is applied here, on the GPU.
+    `pad_to` pads every leaf batch to one fixed size, so that MIOpen tunes its convolutions once
+    instead of once per batch size (the number of leaves changes from wave to wave)."""
     model.eval()
     recurrent = bool(getattr(model, "recurrent", False))
 
     def ev(images):
+        n = images.shape[0]
+        if pad_to is not None and n < pad_to:
+            images = torch.cat([images, images.new_zeros((pad_to - n,) + tuple(images.shape[1:]))], 0)
         with torch.no_grad():
             if recurrent:
                 (p, v), _ = model(images, recurrent_iterations)
             else:
                 p, v = model(images)
         probs = torch.softmax(p.reshape(p.shape[0], -1).float(), dim=1)
-        return probs, v.reshape(-1).float()
+        return probs[:n].contiguous(), v.reshape(-1).float()[:n].contiguous()
     return ev
 
 
