@@ -327,6 +327,32 @@ nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree
                                int32_t* child_visit, double* child_prior, double* child_value_sum,
                                int64_t* counters_host, void* stream);
 
+/* ---- policy/value network on boards of any size (SCS maps) -------------------
+ * The square-conv (hex=False) RecurrentNet / ResNet / ConvNet of the reference
+ * (Neural_Networks/Architectures/RecurrentNet.py:18-99, ResNet.py:13-70, ConvNet.py:12-57,
+ * blocks.py) on rows x cols boards, evaluated on a batch of state images: what
+ * Network_Manager.inference (Network_Manager.py:46-64) plus the softmax of
+ * Explorer.evaluate (Explorer.py:158-162) compute for one position, for n positions.
+ * Every convolution is an implicit-GEMM FP32 MFMA kernel; activations stay on the device.
+ *   images_dev  float[n][in_channels][rows][cols]   (Game.generate_network_input)
+ *   logits_dev  float[n][policy_channels*rows*cols] raw policy logits, may be NULL
+ *   probs_dev   float[n][policy_channels*rows*cols] softmax over ALL logits, may be NULL
+ *   value_dev   float[n]
+ *   n_dev       optional device int32: the live batch size (<= n) when the host does not
+ *               know it yet (the leaf count of a simulation wave); NULL = n. */
+typedef struct nz_boardnet nz_boardnet;
+nz_status nz_boardnet_create(nz_boardnet** out, const nz_net_desc* net, int32_t rows, int32_t cols,
+                             int32_t max_batch, int32_t device);
+void nz_boardnet_destroy(nz_boardnet* h);
+const char* nz_boardnet_last_error(const nz_boardnet* h);
+/* weights: the state_dict tensors in order (float32, device or host), as nz_engine_set_weights */
+nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, int32_t n_weights,
+                                  int32_t recurrent_iterations);
+nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
+                              float* logits_dev, float* probs_dev, float* value_dev, void* stream);
+/* algorithmic FLOPs of one position (taps that fall off the board are not counted) */
+int64_t nz_boardnet_flops(const nz_boardnet* h);
+
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream
  * (Explorer.py:77-78,89,199,208). */

@@ -107,6 +107,12 @@ SIGNATURES = {
     "nz_scs_search_end_move": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_status": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_export": (c_int32, [c_void_p] + [c_void_p] * 9 + [POINTER(c_int64), c_void_p]),
+    "nz_boardnet_create": (c_int32, [POINTER(c_void_p), POINTER(NetDesc), c_int32, c_int32, c_int32, c_int32]),
+    "nz_boardnet_destroy": (None, [c_void_p]),
+    "nz_boardnet_last_error": (c_char_p, [c_void_p]),
+    "nz_boardnet_set_weights": (c_int32, [c_void_p, POINTER(c_void_p), c_int32, c_int32]),
+    "nz_boardnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_boardnet_flops": (c_int64, [c_void_p]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

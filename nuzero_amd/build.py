@@ -23,6 +23,7 @@ UNITS = [
     ("engine.hip", ["-ffp-contract=off"]),
     ("scs.hip", ["-ffp-contract=off"]),
     ("scs_search.hip", ["-ffp-contract=off"]),
+    ("boardnet.hip", []),
     ("rng_host.cpp", ["-ffp-contract=off"]),
 ]
 HEADERS = ["engine.h", "tree_dev.hpp", "net_dev.hpp", "scs_dev.hpp", os.path.join("..", "..", "include", "nuzero_amd.h")]

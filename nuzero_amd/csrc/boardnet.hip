@@ -1,0 +1,477 @@
+// Policy/value network for boards of any size (the SCS maps: 5x5 ... 10x10, 86+ input planes):
+// the square-conv (hex=False) RecurrentNet / ResNet / ConvNet of the reference evaluated on the
+// gathered leaf batch of a simulation wave (C ABI nz_boardnet_*).
+//
+// The fused whole-network kernel of net_dev.hpp keeps a 3x3 board's activations in LDS; a 10x10
+// board with 256 filters does not fit, so here every convolution is its own launch and the
+// activations live in HBM/L2 in position-major, channel-minor order ("NHWC": row = position *
+// H*W + cell, channels contiguous and padded to a multiple of 16).  A convolution is an implicit
+// GEMM on the FP32 matrix cores: rows = board cells of all positions, K = 9 taps x input
+// channels, columns = output channels.
+//   * A operand (activations): lane (row r = lane & 15, k-quarter q = lane >> 4) loads the four
+//     channels 16 kg + 4 q .. + 3 of the tap's neighbour cell as one 16-byte load; a tap that
+//     falls off the board contributes zeros (zero 'same' padding, RecurrentNet.py:47-52).
+//   * B operand (weights): packed on the host per (column tile, tap, channel group) in exactly
+//     the per-lane order v_mfma_f32_16x16x4_f32 wants, so one coalesced 16-byte load per lane.
+//   * one wavefront owns MT x 16 rows and NT x 16 output channels; a workgroup is 4 wavefronts
+//     on consecutive row tiles that share the weight stream through L1/L2.
+//   * epilogue: residual add (blocks.py:37-41), activation, NHWC store.
+// torch.cat([thought, x]) of the recall connection (RecurrentNet.py:91) is never materialised:
+// the K loop runs over two sources.
+//
+// Reference (paths relative to the reference repo): Neural_Networks/Architectures/
+// RecurrentNet.py:18-99, ResNet.py:13-70, ConvNet.py:12-57, blocks.py:12-41 (BasicBlock),
+// 46-92 (Reduce_ValueHead), 130-170 (Reduce_PolicyHead); Network_Manager.py:46-64 (inference);
+// Search/Explorer.py:158-162 (softmax over all logits, value .item()).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nuzero_amd.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* src0;     // [rows][c0] NHWC, c0 a multiple of 16
+  const float* src1;     // second K source (recall concat) or nullptr
+  const float* w;        // packed [ntile][tap][kg0 + kg1][64 lanes][4]
+  const float* res;      // residual [rows][cd] or nullptr
+  float* dst;            // [rows][cd]
+  const int32_t* n_dev;  // live positions on the device (nullptr: n_host)
+  int32_t n_host, hw, h, wd;
+  int32_t c0, c1;        // K extent of each source in channels (multiples of 16)
+  int32_t s0, s1, cd;    // channel strides of the sources and of dst
+  int32_t act;           // 0 none, 1 relu, 2 tanh, 3 elu
+};
+
+__device__ __forceinline__ float activate(float v, int act) {
+  switch (act) {
+    case 1: return v > 0.f ? v : 0.f;
+    case 2: return tanhf(v);
+    case 3: return v > 0.f ? v : expm1f(v);
+    default: return v;
+  }
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int n_pos = p.n_dev ? *p.n_dev : p.n_host;
+  const int M = n_pos * p.hw;
+  const int m0 = (blockIdx.x * 4 + wave) * 16 * MT;
+  if (m0 >= M) return;                               // whole wavefront out of range (uniform)
+  const int nt0 = blockIdx.y * NT;
+  const int kg0 = p.c0 >> 4, kg1 = p.src1 ? (p.c1 >> 4) : 0, kgt = kg0 + kg1;
+
+  int row[MT], cy[MT], cx[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    row[m] = m0 + m * 16 + (lane & 15);
+    const int cell = row[m] % p.hw;
+    cy[m] = row[m] < M ? cell / p.wd : -4;            // rows past the end never match a tap
+    cx[m] = cell % p.wd;
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const size_t tile_stride = (size_t)9 * kgt * 256;    // floats per column tile
+  const float* wbase = p.w + (size_t)nt0 * tile_stride + lane * 4;
+  const int q4 = (lane >> 4) * 4;
+
+  for (int tap = 0; tap < 9; ++tap) {
+    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+    int nbr[MT];
+    bool any = false;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const bool ok = (unsigned)(cy[m] + dy) < (unsigned)p.h && (unsigned)(cx[m] + dx) < (unsigned)p.wd;
+      nbr[m] = ok ? row[m] + dy * p.wd + dx : -1;
+      any |= ok;
+    }
+    if (!__any(any)) continue;                        // the whole tile is off the board for this tap
+    const float* wt = wbase + (size_t)tap * kgt * 256;
+    for (int src = 0; src < 2; ++src) {
+      const float* s = src ? p.src1 : p.src0;
+      const int cs = src ? p.s1 : p.s0;
+      const int kgn = src ? kg1 : kg0;
+      const float* wk = wt + (size_t)(src ? kg0 : 0) * 256;
+      if (kgn == 0) continue;
+      f32x4 a[2][MT], b[2][NT];
+      auto load = [&](int buf, int kg) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (nbr[m] >= 0) a[buf][m] = *reinterpret_cast<const f32x4*>(s + (size_t)nbr[m] * cs + kg * 16 + q4);
+          else a[buf][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[buf][n] = *reinterpret_cast<const f32x4*>(wk + n * tile_stride + (size_t)kg * 256);
+      };
+      auto mac = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][m][j], b[buf][n][j], acc[m][n], 0, 0, 0);
+      };
+      load(0, 0);
+      int kg = 0;
+      for (; kg + 2 <= kgn; kg += 2) {                // ping-pong: the next group's loads fly under the MFMAs
+        load(1, kg + 1);
+        mac(0);
+        if (kg + 2 < kgn) load(0, kg + 2);
+        mac(1);
+      }
+      if (kg < kgn) mac(0);
+    }
+  }
+
+  const int col = lane & 15, r4 = (lane >> 4) * 4;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int orow = m0 + m * 16 + r4 + r;
+      if (orow >= M) continue;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const size_t o = (size_t)orow * p.cd + (nt0 + n) * 16 + col;
+        float v = acc[m][n][r];
+        if (p.res) v += p.res[o];
+        p.dst[o] = activate(v, p.act);
+      }
+    }
+}
+
+// [n][C][H*W] (what Game.generate_network_input stacks) -> [n * H*W][cp], channels zero-padded.
+__global__ void nchw_to_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* n_dev,
+                                    int n_host, int c, int cp, int hw) {
+  const int n_pos = n_dev ? *n_dev : n_host;
+  const size_t total = (size_t)n_pos * hw * cp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % cp);
+    const size_t r = i / cp;
+    const int cell = (int)(r % hw);
+    const size_t n = r / hw;
+    out[i] = ch < c ? in[(n * c + ch) * hw + cell] : 0.f;
+  }
+}
+
+// One wavefront per position: logits in the reference's action order (plane-major: action =
+// plane * H*W + cell), softmax over ALL of them (Explorer.py:159), value = tanh(mean)
+// (blocks.py:82-84).
+__global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ pol, int pp, int planes,
+                                                      const float* __restrict__ val, int vp, int hw,
+                                                      const int32_t* n_dev, int n_host, float* __restrict__ logits,
+                                                      float* __restrict__ probs, float* __restrict__ value) {
+  const int n_pos = n_dev ? *n_dev : n_host;
+  const int n = blockIdx.x;
+  if (n >= n_pos) return;
+  const int lane = threadIdx.x;
+  const int A = planes * hw;
+  const float* pr = pol + (size_t)n * hw * pp;
+  float mx = -INFINITY;
+  for (int a = lane; a < A; a += 64) {
+    const float v = pr[(a % hw) * pp + a / hw];
+    if (logits) logits[(size_t)n * A + a] = v;
+    mx = fmaxf(mx, v);
+  }
+  for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (probs) {
+    float sum = 0.f;
+    for (int a = lane; a < A; a += 64) {
+      const float e = expf(pr[(a % hw) * pp + a / hw] - mx);
+      probs[(size_t)n * A + a] = e;
+      sum += e;
+    }
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    for (int a = lane; a < A; a += 64) probs[(size_t)n * A + a] /= sum;
+  }
+  float s = 0.f;
+  for (int c = lane; c < hw; c += 64) s += val[((size_t)n * hw + c) * vp];
+  for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) value[n] = tanhf(s / (float)hw);
+}
+
+struct ConvOp {
+  int src0, src1, res, dst;     // buffer ids (-1: none)
+  int weight;                   // index into packed weights
+  int act;
+};
+
+struct PackedConv {
+  float* dev = nullptr;
+  int c0p = 0, c1p = 0, coutp = 0, cout = 0, cin = 0;
+};
+
+}  // namespace
+
+struct nz_boardnet {
+  int device = 0;
+  nz_net_desc net{};
+  int rows = 0, cols = 0, hw = 0, max_batch = 0;
+  int inp = 0;                              // padded input channels
+  int widthp = 0;
+  std::vector<float*> buffers;              // 0: input rows, 1..3: trunk, 4: policy hidden, 5: policy logits, 6,7: value chain
+  std::vector<int> buffer_channels;
+  std::vector<PackedConv> convs;
+  std::vector<ConvOp> ops;
+  int policy_buf = -1, value_buf = -1;
+  bool ready = false;
+  int64_t flops = 0;
+  std::string error;
+};
+
+namespace {
+std::string g_err;
+nz_status bfail(nz_boardnet* h, nz_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  (h ? h->error : g_err) = buf;
+  return st;
+}
+#define B_HIP(h, call)                                                                            \
+  do {                                                                                            \
+    hipError_t e__ = (call);                                                                      \
+    if (e__ != hipSuccess) return bfail((h), NZ_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e__)); \
+  } while (0)
+
+int pad16(int c) { return (c + 15) / 16 * 16; }
+
+std::vector<int> head_channels(int width, int out, int layers) {   // blocks.py:56-66,144-153
+  std::vector<int> ch{width};
+  const double step = (double)(out - width) / layers;
+  double prev = width;
+  for (int i = 0; i < layers; ++i) { prev += step; ch.push_back((int)prev); }
+  return ch;
+}
+
+// weights [cout][c0 + c1][k][k] (k = 1 or 3) -> the per-lane stream conv_kernel reads.
+bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c0p, int c1p) {
+  PackedConv pc;
+  pc.cout = cout; pc.coutp = pad16(cout); pc.cin = c0 + c1; pc.c0p = c0p; pc.c1p = c1p;
+  const int ntiles = pc.coutp / 16, kgt = (c0p + c1p) / 16;
+  std::vector<float> host((size_t)ntiles * 9 * kgt * 256, 0.f);
+  std::vector<float> wh((size_t)cout * (c0 + c1) * k * k);
+  if (hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return false;
+  for (int nt = 0; nt < ntiles; ++nt)
+    for (int tap = 0; tap < 9; ++tap) {
+      if (k == 1 && tap != 4) continue;
+      const int wt = k == 1 ? 0 : tap;
+      for (int kg = 0; kg < kgt; ++kg)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int co = nt * 16 + (lane & 15);
+            int ch = kg * 16 + (lane >> 4) * 4 + j;          // channel within the padded concat
+            int cin_idx;
+            if (ch < c0p) cin_idx = ch < c0 ? ch : -1;
+            else { ch -= c0p; cin_idx = ch < c1 ? c0 + ch : -1; }
+            if (co >= cout || cin_idx < 0) continue;
+            host[(((size_t)nt * 9 + tap) * kgt + kg) * 256 + lane * 4 + j] =
+                wh[((size_t)co * (c0 + c1) + cin_idx) * k * k + wt];
+          }
+    }
+  if (hipMalloc((void**)&pc.dev, host.size() * sizeof(float)) != hipSuccess) return false;
+  if (hipMemcpy(pc.dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+  h->convs.push_back(pc);
+  // algorithmic flops per position: taps inside the board only
+  const int64_t taps = k == 1 ? (int64_t)h->hw : (int64_t)(3 * h->rows - 2) * (3 * h->cols - 2);
+  h->flops += 2 * taps * (c0 + c1) * cout;
+  return true;
+}
+
+template <int MT, int NT>
+void launch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
+  const int rows_max = a.n_host * a.hw;
+  dim3 grid((rows_max + 64 * MT - 1) / (64 * MT), ntiles / NT);
+  hipLaunchKernelGGL((conv_kernel<MT, NT>), grid, dim3(256), 0, s, a);
+}
+
+void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
+  const bool big = (int64_t)a.n_host * a.hw >= 64 * 2 * 256;     // enough rows to fill 256 CUs with 32-row tiles
+  int nt = ntiles % 4 == 0 ? 4 : ntiles % 3 == 0 ? 3 : ntiles % 2 == 0 ? 2 : 1;
+#define CASE(MTV, NTV) launch_conv<MTV, NTV>(a, ntiles, s)
+  if (big) { if (nt == 4) CASE(2, 4); else if (nt == 3) CASE(2, 3); else if (nt == 2) CASE(2, 2); else CASE(2, 1); }
+  else { if (nt == 4) CASE(1, 4); else if (nt == 3) CASE(1, 3); else if (nt == 2) CASE(1, 2); else CASE(1, 1); }
+#undef CASE
+}
+}  // namespace
+
+extern "C" {
+
+const char* nz_boardnet_last_error(const nz_boardnet* h) { return h ? h->error.c_str() : g_err.c_str(); }
+
+void nz_boardnet_destroy(nz_boardnet* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (float* b : h->buffers) (void)hipFree(b);
+  for (auto& c : h->convs) (void)hipFree(c.dev);
+  delete h;
+}
+
+nz_status nz_boardnet_create(nz_boardnet** out, const nz_net_desc* net, int32_t rows, int32_t cols,
+                             int32_t max_batch, int32_t device) {
+  if (!out || !net) return bfail(nullptr, NZ_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (rows <= 0 || cols <= 0 || max_batch <= 0 || net->in_channels <= 0 || net->policy_channels <= 0 ||
+      net->width <= 0 || net->num_blocks < 0)
+    return bfail(nullptr, NZ_ERR_ARG, "bad sizes");
+  if (net->arch != NZ_ARCH_RECURRENT && net->arch != NZ_ARCH_RESNET && net->arch != NZ_ARCH_CONVNET)
+    return bfail(nullptr, NZ_ERR_ARG, "unknown architecture %d", net->arch);
+  if (net->arch == NZ_ARCH_CONVNET && net->kernel_size != 1 && net->kernel_size != 3)
+    return bfail(nullptr, NZ_ERR_ARG, "ConvNet kernel_size must be 1 or 3");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
+    return bfail(nullptr, NZ_ERR_HIP, "no HIP device %d (no CPU fallback)", device);
+  (void)hipSetDevice(device);
+  nz_boardnet* h = new nz_boardnet;
+  h->device = device; h->net = *net; h->rows = rows; h->cols = cols; h->hw = rows * cols; h->max_batch = max_batch;
+  h->inp = pad16(net->in_channels);
+  h->widthp = pad16(net->width);
+  const std::vector<int> pc = head_channels(net->width, net->policy_channels, 2);
+  const std::vector<int> vc = head_channels(net->width, 1, 4);
+  int vmax = 16;
+  for (size_t i = 1; i < vc.size(); ++i) vmax = std::max(vmax, pad16(vc[i]));
+  h->buffer_channels = {h->inp, h->widthp, h->widthp, h->widthp, pad16(pc[1]), pad16(pc[2]), vmax, vmax};
+  for (int c : h->buffer_channels) {
+    float* b = nullptr;
+    const size_t n = (size_t)max_batch * h->hw * c;
+    if (hipMalloc((void**)&b, n * sizeof(float)) != hipSuccess || hipMemset(b, 0, n * sizeof(float)) != hipSuccess) {
+      nz_boardnet_destroy(h);
+      return bfail(nullptr, NZ_ERR_HIP, "device allocation failed");
+    }
+    h->buffers.push_back(b);
+  }
+  *out = h;
+  return NZ_OK;
+}
+
+// weights: the reference's state_dict tensors in order (device or host pointers), float32.
+nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, int32_t n_weights,
+                                  int32_t recurrent_iterations) {
+  if (!h || !weights) return NZ_ERR_ARG;
+  B_HIP(h, hipSetDevice(h->device));
+  B_HIP(h, hipDeviceSynchronize());
+  for (auto& c : h->convs) (void)hipFree(c.dev);
+  h->convs.clear(); h->ops.clear(); h->flops = 0; h->ready = false;
+  const nz_net_desc& nd = h->net;
+  const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
+  const int vact = nd.value_activation == NZ_ACT_RELU ? 1 : 2;
+  int wi = 0;
+  auto add = [&](int cout, int c0, int c1, int k, int c0p, int c1p, int src0, int src1, int res, int dst, int act) {
+    if (!pack(h, weights[wi], cout, c0, c1, k, c0p, c1p)) return false;
+    h->ops.push_back(ConvOp{src0, src1, res, dst, wi, act});
+    ++wi;
+    return true;
+  };
+  bool ok = true;
+  int cur = 1;                                  // trunk buffer holding the current activations
+  auto block = [&](int w0) {                    // BasicBlock: relu(conv(relu(conv(t))) + t)
+    const int y = cur % 3 + 1, o = y % 3 + 1;
+    (void)w0;
+    ok = ok && add(W, W, 0, 3, Wp, 0, cur, -1, -1, y, 1) && add(W, W, 0, 3, Wp, 0, y, -1, cur, o, 1);
+    cur = o;
+  };
+  if (nd.arch == NZ_ARCH_RECURRENT) {
+    const int per_iter = (nd.recall ? 1 : 0) + 2 * nd.num_blocks;
+    if (n_weights != 1 + per_iter + 6) return bfail(h, NZ_ERR_ARG, "RecurrentNet needs %d tensors, got %d", 1 + per_iter + 6, n_weights);
+    if (recurrent_iterations < 1) return bfail(h, NZ_ERR_ARG, "recurrent_iterations must be >= 1");
+    ok = add(W, IN, 0, 3, INp, 0, 0, -1, -1, 1, 1);
+    const int first = wi;
+    for (int it = 0; it < recurrent_iterations && ok; ++it) {
+      wi = first;
+      if (nd.recall) {
+        const int o = cur % 3 + 1;
+        ok = ok && add(W, W, IN, 3, Wp, INp, cur, 0, -1, o, 0);
+        cur = o;
+      }
+      for (int b = 0; b < nd.num_blocks && ok; ++b) block(wi);
+    }
+    wi = first + per_iter;
+  } else if (nd.arch == NZ_ARCH_RESNET) {
+    if (n_weights != 1 + 2 * nd.num_blocks + 6) return bfail(h, NZ_ERR_ARG, "ResNet needs %d tensors, got %d", 1 + 2 * nd.num_blocks + 6, n_weights);
+    ok = add(W, IN, 0, 3, INp, 0, 0, -1, -1, 1, 1);
+    for (int b = 0; b < nd.num_blocks && ok; ++b) block(wi);
+  } else {
+    if (n_weights != 1 + nd.num_blocks + 6) return bfail(h, NZ_ERR_ARG, "ConvNet needs %d tensors, got %d", 1 + nd.num_blocks + 6, n_weights);
+    const int k = nd.kernel_size;
+    ok = add(W, IN, 0, k, INp, 0, 0, -1, -1, 1, 3);
+    for (int i = 0; i < nd.num_blocks && ok; ++i) {
+      const int o = cur % 3 + 1;
+      ok = ok && add(W, W, 0, k, Wp, 0, cur, -1, -1, o, 3);
+      cur = o;
+    }
+  }
+  const std::vector<int> pc = head_channels(W, nd.policy_channels, 2);
+  const std::vector<int> vc = head_channels(W, 1, 4);
+  for (size_t i = 1; i < pc.size(); ++i)
+    if (pc[i] <= 0) return bfail(h, NZ_ERR_ARG, "policy head channel schedule reaches %d", pc[i]);
+  ok = ok && add(pc[1], W, 0, 3, Wp, 0, cur, -1, -1, 4, 1) && add(pc[2], pc[1], 0, 3, pad16(pc[1]), 0, 4, -1, -1, 5, 0);
+  int vsrc = cur;
+  for (int i = 0; i < 4 && ok; ++i) {
+    if (vc[i + 1] <= 0) return bfail(h, NZ_ERR_ARG, "value head channel schedule reaches %d", vc[i + 1]);
+    const int dst = 6 + (i & 1);
+    ok = add(vc[i + 1], vc[i], 0, 3, pad16(vc[i]), 0, vsrc, -1, -1, dst, i == 3 ? 0 : vact);
+    vsrc = dst;
+  }
+  if (!ok) return bfail(h, NZ_ERR_HIP, "weight upload failed");
+  h->policy_buf = 5; h->value_buf = vsrc;
+  h->ready = true;
+  return NZ_OK;
+}
+
+int64_t nz_boardnet_flops(const nz_boardnet* h) { return h ? h->flops : 0; }
+
+nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
+                              float* logits_dev, float* probs_dev, float* value_dev, void* stream) {
+  if (!h || !images_dev || !value_dev) return NZ_ERR_ARG;
+  if (!h->ready) return bfail(h, NZ_ERR_STATE, "no weights set");
+  if (n < 0 || n > h->max_batch) return bfail(h, NZ_ERR_ARG, "batch %d exceeds max_batch %d", n, h->max_batch);
+  if (n == 0) return NZ_OK;
+  B_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t total = (size_t)n * h->hw * h->inp;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
+                     h->net.in_channels, h->inp, h->hw);
+  for (const ConvOp& op : h->ops) {
+    const PackedConv& pc = h->convs[&op - h->ops.data()];
+    ConvArgs a;
+    a.src0 = h->buffers[op.src0];
+    a.src1 = op.src1 >= 0 ? h->buffers[op.src1] : nullptr;
+    a.w = pc.dev;
+    a.res = op.res >= 0 ? h->buffers[op.res] : nullptr;
+    a.dst = h->buffers[op.dst];
+    a.n_dev = n_dev; a.n_host = n; a.hw = h->hw; a.h = h->rows; a.wd = h->cols;
+    a.c0 = pc.c0p; a.c1 = pc.c1p;
+    a.s0 = h->buffer_channels[op.src0];
+    a.s1 = op.src1 >= 0 ? h->buffer_channels[op.src1] : 0;
+    a.cd = h->buffer_channels[op.dst];
+    a.act = op.act;
+    if (a.c0 > a.s0 || a.c1 > a.s1 || pc.coutp > a.cd) return bfail(h, NZ_ERR_STATE, "internal: layer shapes disagree");
+    dispatch_conv(a, pc.coutp / 16, s);
+  }
+  hipLaunchKernelGGL(finalize_kernel, dim3(n), dim3(64), 0, s, h->buffers[h->policy_buf], h->buffer_channels[h->policy_buf],
+                     h->net.policy_channels, h->buffers[h->value_buf], h->buffer_channels[h->value_buf], h->hw, n_dev, n,
+                     logits_dev, probs_dev, value_dev);
+  B_HIP(h, hipGetLastError());
+  return NZ_OK;
+}
+
+}  // extern "C"

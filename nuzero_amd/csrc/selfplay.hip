@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
   RootCache rc;
   root_cache_load(rc, t, 0, sub);
   int outcome = 0;
-  unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0, t_expand = 0;
+  unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0;
   if constexpr (STAMPS) t_begin = t0 = __builtin_amdgcn_s_memtime();
 
   __shared__ int s_max_sims;
@@ -81,8 +81,6 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       __syncthreads();
     }
     if (alive) {
-      unsigned long long te0 = 0;
-      if constexpr (STAMPS) te0 = __builtin_amdgcn_s_memtime();
       if (pending) {
         const float logit = sub < 9 ? out_logits[slot * TTT_ACTIONS + sub] : 0.0f;
         const float prob = row_softmax9(logit, sub);
@@ -97,7 +95,6 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
         ++n_exp;
         pending = false;
       }
-      if constexpr (STAMPS) t_expand += __builtin_amdgcn_s_memtime() - te0;
       while (alive && !pending && cyc_sims < p.sims_per_cycle) {
         if (move < 0) {
           // ---- the slot's game is over: record it, take the next one of the round ----

@@ -58,6 +58,11 @@ def net_kat2():
     return dict(np.load(os.path.join(GOLDEN, "net_kat2.npz")))
 
 
+@pytest.fixture(scope="session")
+def net_kat3():
+    return dict(np.load(os.path.join(GOLDEN, "net_kat3.npz")))
+
+
 NETS2 = {"D": ("resnet", 3, 32, 3, 3, 2.0), "E": ("convnet", 4, 32, 3, 3, 2.0), "F": ("convnet", 5, 48, 2, 1, 2.0)}
 
 
@@ -66,3 +71,46 @@ def nets2_weights(name):
     arch, seed, width, depth, k, gain = NETS2[name]
     shapes = resnet_param_shapes(2, 1, width, depth) if arch == "resnet" else convnet_param_shapes(2, 1, k, width, depth)
     return synthetic_weights(seed, shapes, gain)
+
+
+# board-sized nets (SCS shapes), as tests/golden/make_golden.py NETS3:
+# name -> (arch, seed, in, planes, rows, cols, width, depth, recall, value_activation, iters, positions, gain)
+NETS3 = {
+    "G": ("recurrent", 11, 86, 21, 5, 5, 32, 2, True, "tanh", 2, 6, 2.0),
+    "H": ("resnet", 12, 105, 30, 6, 5, 48, 2, False, "relu", 1, 4, 2.0),
+    "I": ("convnet", 13, 86, 21, 10, 10, 32, 3, False, "tanh", 1, 3, 2.0),
+    "J": ("recurrent", 14, 86, 21, 5, 5, 64, 1, False, "relu", 3, 5, 2.0),
+}
+
+
+def nets3_weights(name):
+    from nuzero_amd.weights import (synthetic_weights, resnet_param_shapes, convnet_param_shapes,
+                                    recurrent_net_param_shapes)
+    arch, seed, cin, planes, rows, cols, width, depth, recall, vact, iters, n, gain = NETS3[name]
+    if arch == "recurrent":
+        shapes = recurrent_net_param_shapes(cin, planes, width, depth, recall)
+    elif arch == "resnet":
+        shapes = resnet_param_shapes(cin, planes, width, depth)
+    else:
+        shapes = convnet_param_shapes(cin, planes, 3, width, depth)
+    return synthetic_weights(seed, shapes, gain)
+
+
+def nets3_inputs(name, n=None, offset=0):
+    """The generator's inputs (offset 0, n = positions of the case) or more of the same kind."""
+    import numpy as np
+    _, seed, cin, _, rows, cols, *_rest = NETS3[name]
+    n = NETS3[name][11] if n is None else n
+    rs = np.random.RandomState(1000 + seed + offset)
+    x = (rs.random_sample((n, cin, rows, cols)) < 0.15).astype(np.float32)
+    x[:, -3:] = rs.random_sample((n, 3, rows, cols)).astype(np.float32)
+    return x
+
+
+def nets3_oracle(name):
+    from oracle.net import RecurrentNetRef, FeedForwardRef
+    arch, seed, cin, planes, rows, cols, width, depth, recall, vact, iters, n, gain = NETS3[name]
+    w = nets3_weights(name)
+    if arch == "recurrent":
+        return RecurrentNetRef(w, cin, planes, width, depth, recall, vact)
+    return FeedForwardRef(w, arch, depth, vact)

@@ -60,7 +60,7 @@ from Neural_Networks.Architectures.ResNet import ResNet  # noqa: E402
 from Neural_Networks.Architectures.ConvNet import ConvNet  # noqa: E402
 
 from nuzero_amd.weights import (synthetic_recurrent_net_weights, synthetic_weights,  # noqa: E402
-                                resnet_param_shapes, convnet_param_shapes)
+                                resnet_param_shapes, convnet_param_shapes, recurrent_net_param_shapes)
 
 tic_tac_toe.generate_network_input = tic_tac_toe.generate_state_image  # HEAD drift shim
 torch.set_num_threads(1)
@@ -259,6 +259,57 @@ def gen_nets2(reach):
     return {k: list(v) for k, v in NETS2.items()}
 
 
+# board-sized nets (the SCS shapes): name -> (arch, seed, in, planes, rows, cols, width, depth, recall,
+# value_activation, iters, positions, gain)
+NETS3 = {
+    "G": ("recurrent", 11, 86, 21, 5, 5, 32, 2, True, "tanh", 2, 6, 2.0),
+    "H": ("resnet", 12, 105, 30, 6, 5, 48, 2, False, "relu", 1, 4, 2.0),
+    "I": ("convnet", 13, 86, 21, 10, 10, 32, 3, False, "tanh", 1, 3, 2.0),
+    "J": ("recurrent", 14, 86, 21, 5, 5, 64, 1, False, "relu", 3, 5, 2.0),
+}
+
+
+def nets3_inputs(name):
+    """Sparse 0/1 planes plus a few fractional ones, like SCS state images."""
+    _, seed, cin, _, rows, cols, *_rest = NETS3[name]
+    n = NETS3[name][11]
+    rs = np.random.RandomState(1000 + seed)
+    x = (rs.random_sample((n, cin, rows, cols)) < 0.15).astype(np.float32)
+    x[:, -3:] = rs.random_sample((n, 3, rows, cols)).astype(np.float32)
+    return x
+
+
+def gen_nets3():
+    """hex=False RecurrentNet / ResNet / ConvNet on SCS-sized inputs through Network_Manager.inference."""
+    out = {}
+    for name, (arch, seed, cin, planes, rows, cols, width, depth, recall, vact, iters, n, gain) in NETS3.items():
+        if arch == "recurrent":
+            w = synthetic_weights(seed, recurrent_net_param_shapes(cin, planes, width, depth, recall), gain)
+            net = RecurrentNet(cin, planes, width, depth, recall=recall, value_activation=vact, hex=False)
+        elif arch == "resnet":
+            w = synthetic_weights(seed, resnet_param_shapes(cin, planes, width, depth), gain)
+            net = ResNet(cin, planes, num_filters=width, num_blocks=depth, value_activation=vact, hex=False)
+        else:
+            w = synthetic_weights(seed, convnet_param_shapes(cin, planes, 3, width, depth), gain)
+            net = ConvNet(cin, planes, kernel_size=3, num_filters=width, num_layers=depth, hex=False)
+        sd = net.state_dict()
+        assert list(sd.keys()) == list(w.keys()), (list(sd.keys()), list(w.keys()))
+        net.load_state_dict({kk: torch.from_numpy(v) for kk, v in w.items()})
+        nm = Network_Manager(net)
+        x = nets3_inputs(name)
+        logits = np.zeros((n, planes * rows * cols), np.float32)
+        probs = np.zeros_like(logits)
+        vals = np.zeros((n,), np.float32)
+        for i in range(n):
+            state = torch.from_numpy(x[i:i + 1])
+            p, v = nm.inference(state, False, iters) if arch == "recurrent" else nm.inference(state, False)
+            assert tuple(p.shape) == (1, planes, rows, cols)
+            logits[i], probs[i], vals[i] = p.numpy().reshape(-1), softmax(p).reshape(-1), v.item()
+        out[f"{name}_logits"], out[f"{name}_probs"], out[f"{name}_value"] = logits, probs, vals
+    np.savez_compressed(os.path.join(HERE, "net_kat3.npz"), **out)
+    return {k: list(v) for k, v in NETS3.items()}
+
+
 # --------------------------------------------------------------------------- search
 class TableCache:
     """Cache-shaped object that always hits (Explorer.py:146-149)."""
@@ -454,6 +505,9 @@ def main():
     if "--only-nets2" in sys.argv:          # added later; leaves the other fixtures byte-identical
         print(json.dumps(gen_nets2(reachable()), indent=1))
         return
+    if "--only-nets3" in sys.argv:
+        print(json.dumps(gen_nets3(), indent=1))
+        return
     meta = {"numpy": np.__version__, "scipy": scipy.__version__, "torch": torch.__version__,
             "python": sys.version.split()[0],
             "shims": ["termcolor stand-in", "hexagdly stand-in (hex=False only)",
@@ -464,6 +518,7 @@ def main():
     reach = reachable()
     codes, tables = gen_nets(reach)
     meta["nets2"] = gen_nets2(reach)
+    meta["nets3"] = gen_nets3()
     meta["search"] = gen_search(codes, tables)
     meta["unit"] = gen_unit()
     with open(os.path.join(HERE, "meta.json"), "w") as f:

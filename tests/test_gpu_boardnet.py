@@ -1,0 +1,137 @@
+"""The board-sized policy/value network kernels (nz_boardnet_*, nuzero_amd/csrc/boardnet.hip)
+against the reference's own outputs (tests/golden/net_kat3.npz) and against the oracle nets
+(oracle/net.py, pinned bit-exactly to the reference by tests/test_oracle_golden.py).
+
+Tolerance: 1e-5 absolute on softmax probabilities and values (BASELINE.json north_star);
+raw logits are compared relative to the largest logit of the position.  Needs a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import NETS3, nets3_inputs, nets3_oracle, nets3_weights
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _boardnet(name, max_batch):
+    from nuzero_amd.boardnet import BoardNet
+    arch, seed, cin, planes, rows, cols, width, depth, recall, vact, iters, n, gain = NETS3[name]
+    net = BoardNet(arch, cin, planes, rows, cols, width=width, num_blocks=depth, recall=recall,
+                   value_activation=vact, kernel_size=3, max_batch=max_batch)
+    net.set_weights(nets3_weights(name), iters)
+    return net, iters
+
+
+def _check(probs, value, logits, want_probs, want_value, want_logits):
+    scale = np.abs(want_logits).max(axis=1, keepdims=True) + 1.0
+    assert np.max(np.abs(logits - want_logits) / scale) < TOL
+    assert np.max(np.abs(probs - want_probs)) < TOL
+    assert np.max(np.abs(value - want_value)) < TOL
+    assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+def test_boardnet_equals_reference_outputs(net_kat3, name):
+    import torch
+    net, _ = _boardnet(name, 16)
+    x = torch.from_numpy(nets3_inputs(name)).cuda()
+    probs, value, logits = net.forward(x, want_logits=True)
+    _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(),
+           net_kat3[f"{name}_probs"], net_kat3[f"{name}_value"], net_kat3[f"{name}_logits"])
+    net.close()
+
+
+@pytest.mark.parametrize("name,n", [("G", 333), ("H", 70), ("I", 41), ("J", 1500)])
+def test_boardnet_batches_equal_oracle(name, n):
+    """Ragged batch sizes (rows not a multiple of the 16/64-row tiles) and both row-tile shapes."""
+    import torch
+    from scipy.special import softmax
+    net, iters = _boardnet(name, n)
+    x = nets3_inputs(name, n, offset=7)
+    probs, value, logits = net.forward(torch.from_numpy(x).cuda(), want_logits=True)
+    p, v = nets3_oracle(name).inference(x, iters)
+    p = p.reshape(n, -1)
+    _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(), softmax(p, axis=1), v.reshape(-1), p)
+    assert net.flops_per_position > 0
+    net.close()
+
+
+def test_boardnet_device_side_batch_count():
+    """The live batch size can stay on the device (the leaf count of a simulation wave)."""
+    import torch
+    net, _ = _boardnet("G", 64)
+    x = torch.from_numpy(nets3_inputs("G", 64, offset=3)).cuda()
+    full_p, full_v = net.forward(x)
+    n_dev = torch.tensor([37], dtype=torch.int32, device="cuda")
+    from ctypes import c_void_p
+    from nuzero_amd._lib import lib
+    probs = torch.full((64, net.num_actions), -1.0, dtype=torch.float32, device="cuda")
+    value = torch.full((64,), -7.0, dtype=torch.float32, device="cuda")
+    st = lib.nz_boardnet_forward(net._h, c_void_p(x.data_ptr()), 64, c_void_p(n_dev.data_ptr()), None,
+                                 c_void_p(probs.data_ptr()), c_void_p(value.data_ptr()),
+                                 c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    assert torch.equal(probs[:37], full_p[:37]) and torch.equal(value[:37], full_v[:37])
+    assert (probs[37:] == -1.0).all() and (value[37:] == -7.0).all()
+    net.close()
+
+
+def test_boardnet_rejects_bad_arguments():
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd._lib import NzError
+    import torch
+    with pytest.raises(NzError):
+        BoardNet("convnet", 86, 21, 5, 5, width=32, num_blocks=2, kernel_size=5)
+    net = BoardNet("resnet", 86, 21, 5, 5, width=32, num_blocks=2, max_batch=4)
+    with pytest.raises(NzError):          # forward before weights
+        net.forward(torch.zeros((1, 86, 5, 5), device="cuda"))
+    with pytest.raises(NzError):          # wrong tensor count
+        net.set_weights({"a": np.zeros((32, 86, 3, 3), np.float32)})
+    net.close()
+
+
+def test_scs_selfplay_with_the_native_network():
+    """SCS self-play with tree, rules AND network on the device (no PyTorch model in the loop):
+    the first root's priors are the oracle net's softmax over the legal moves of the opening
+    position, and every game replays legally through the oracle rules."""
+    import torch
+    from scipy.special import softmax
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from nuzero_amd.weights import synthetic_weights, resnet_param_shapes
+    from oracle.net import FeedForwardRef
+    from oracle.scs import ScsConfig, ScsGame
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsGameConfig(path)
+    w = synthetic_weights(5, resnet_param_shapes(cfg.channels, cfg.planes, 32, 2), 2.0)
+    net = BoardNet("resnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=2, max_batch=8)
+    net.set_weights(w)
+    search = {"Simulation": {"mcts_simulations": 16, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.0,
+                              "root_dist_alpha": 0.2, "root_dist_beta": 1}}
+    sp = ScsSelfPlay(cfg, search, 8)
+    r = sp.play(net.evaluator(), seeds=range(40, 48))
+    ocfg = ScsConfig(path)
+    og = ScsGame(ocfg)
+    p, _ = FeedForwardRef(w, "resnet", 2).inference(og.state_image(), None)
+    mask = og.possible_actions().reshape(-1)
+    pri = softmax(p).reshape(-1) * mask
+    pri = pri[mask > 0] / pri.sum()
+    k = r["n_children"][0, 0]
+    assert k == int(mask.sum())
+    assert np.max(np.abs(r["child_prior"][0, 0, :k] - pri)) < TOL      # fraction 0: noise leaves the priors alone
+    for g in range(8):
+        og = ScsGame(ocfg)
+        for m in range(r["lengths"][g]):
+            legal = np.nonzero(og.possible_actions().reshape(-1))[0]
+            kk = r["n_children"][g, m]
+            assert r["child_action"][g, m, :kk].tolist() == legal.tolist()
+            og.step_index(int(r["actions"][g, m]))
+        assert og.terminal and og.terminal_value == r["outcomes"][g]
+    assert r["expansions"] == sp.evaluations
+    sp.close()
+    net.close()

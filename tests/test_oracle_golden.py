@@ -197,3 +197,21 @@ def test_feedforward_nets_against_reference(net_kat2, name):
         p, v = net.inference(g.state_image())
         assert np.array_equal(p.reshape(-1), net_kat2[f"{name}_logits"][j])
         assert np.float32(v.reshape(-1)[0]) == net_kat2[f"{name}_value"][j]
+
+
+@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+def test_board_sized_nets_against_reference(net_kat3, name):
+    """The oracle nets on SCS-sized inputs (86/105 planes, 5x5 .. 10x10 boards, 21/30 policy planes)
+    against the reference's RecurrentNet / ResNet / ConvNet (hex=False) through Network_Manager.inference
+    (tests/golden/make_golden.py gen_nets3)."""
+    from conftest import NETS3, nets3_inputs, nets3_oracle
+    from scipy.special import softmax
+    kat = net_kat3
+    iters = NETS3[name][10]
+    net = nets3_oracle(name)
+    x = nets3_inputs(name)
+    for i in range(len(x)):
+        p, v = net.inference(x[i:i + 1], iters)
+        assert np.array_equal(p.reshape(-1), kat[f"{name}_logits"][i])
+        assert np.array_equal(softmax(p).reshape(-1), kat[f"{name}_probs"][i])
+        assert np.float32(v.reshape(-1)[0]) == kat[f"{name}_value"][i]
