@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""First measurement of the SCS self-play path (BASELINE.json configs[3] shape: SCS 5x5 map,
-200 sims/move, 1024 games, 1 GPU).  Not the driver's bench (that is bench.py): the SCS path is
-lock-step with the network outside the search kernels -- tree, rules and legal masks on the
-device (nz_scs_search_*), a PyTorch conv net (square 3x3 convs: hexagdly is not available, so
-the hex form of the reference's ConvNet cannot run or be pinned) evaluating the leaf batch.
+"""Measurement of the SCS self-play path (BASELINE.json configs[3] shape: SCS 5x5 map, 200
+sims/move, 1024 games, 1 GPU).  Not the driver's bench (that is bench.py).  The SCS path is
+lock-step: tree, rules and legal masks on the device (nz_scs_search_*), the leaf batch of every
+simulation wave evaluated by the reference's ConvNet with square 3x3 convs (hexagdly is not
+available, so the hex form cannot run or be pinned) -- either by the hand-written MFMA kernels
+(nz_boardnet_*, --evaluator native) or by PyTorch/MIOpen (--evaluator torch).
 
-    python bench_scs.py [--games 1024] [--sims 200] [--filters 32] [--layers 8]
+    python bench_scs.py [--games 1024] [--sims 200] [--filters 32] [--layers 8] [--evaluator native|torch]
 """
 import argparse
 import json
@@ -25,32 +26,45 @@ def main():
     ap.add_argument("--sims", type=int, default=200)
     ap.add_argument("--filters", type=int, default=32)
     ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--evaluator", choices=["native", "torch"], default="native")
+    ap.add_argument("--loop", choices=["library", "python"], default="library",
+                    help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
     ap.add_argument("--config", default=os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
     args = ap.parse_args()
     import torch
-    from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay, torch_evaluator
+    import torch.nn.functional as F
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
     cfg = ScsGameConfig(args.config)
+    # ConvNet(in, policy, kernel_size=3, num_filters, num_layers, hex=False) with random-init weights
+    w = synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, args.filters, args.layers))
+    if args.evaluator == "native":
+        net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
+                       num_blocks=args.layers, kernel_size=3, max_batch=args.games)
+        net.set_weights(w)
+        ev = net.evaluator()
+    else:
+        torch.backends.cudnn.benchmark = True        # let MIOpen pick a solver for the (fixed) leaf-batch shape
+        wd = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
+        conv = lambda t, name: F.conv2d(t, wd[name], None, 1, "same")
 
-    class ConvNetSquare(torch.nn.Module):            # ConvNet(in, policy, 3, filters, layers, hex=False) trunk + 1-conv heads
-        recurrent = False
-
-        def __init__(self):
-            super().__init__()
-            layers, c = [], cfg.channels
-            for _ in range(args.layers + 1):
-                layers += [torch.nn.Conv2d(c, args.filters, 3, padding="same", bias=False), torch.nn.ELU()]
-                c = args.filters
-            self.trunk = torch.nn.Sequential(*layers)
-            self.policy = torch.nn.Conv2d(c, cfg.planes, 3, padding="same", bias=False)
-            self.value = torch.nn.Conv2d(c, 1, 3, padding="same", bias=False)
-
-        def forward(self, x):
-            t = self.trunk(x)
-            return self.policy(t), torch.tanh(self.value(t).mean(dim=(1, 2, 3))).reshape(-1, 1)
-
-    torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = True        # let MIOpen pick a solver for the (fixed) leaf-batch shape
-    net = ConvNetSquare().cuda()
+        def ev(images):
+            n = images.shape[0]
+            if n < args.games:                       # one batch shape: MIOpen tunes once
+                images = torch.cat([images, images.new_zeros((args.games - n,) + tuple(images.shape[1:]))], 0)
+            with torch.no_grad():
+                t = F.elu(conv(images, "general_module.0.weight"))
+                for i in range(args.layers):
+                    t = F.elu(conv(t, f"general_module.{2 * (i + 1)}.weight"))
+                p = conv(F.relu(conv(t, "policy_head.layers.0.weight")), "policy_head.layers.2.weight")
+                v = t
+                for i in range(4):
+                    v = conv(v, f"value_head.layers.{2 * i}.weight")
+                    if i != 3:
+                        v = torch.tanh(v)
+                probs = torch.softmax(p.reshape(p.shape[0], -1), 1)
+                return probs[:n].contiguous(), torch.tanh(v.mean(dim=(1, 2, 3)))[:n].contiguous()
     search = {"Simulation": {"mcts_simulations": args.sims, "keep_subtree": True},
               "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
               "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
@@ -58,17 +72,20 @@ def main():
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
     sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * 40 * 128)
-    t0 = time.perf_counter()
-    ev = torch_evaluator(net, pad_to=args.games)
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    r = sp.play(ev, seeds=range(args.games))
+    if args.evaluator == "native" and args.loop == "library":
+        r = sp.play_native(net, range(args.games))
+    else:
+        r = sp.play(ev, seeds=range(args.games))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, torch ConvNet(%d filters, %d layers, "
-                                  "square convs) as evaluator" % (cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games,
-                                                                  args.filters, args.layers),
+    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, ConvNet(%d filters, %d layers, "
+                                  "square convs), %s evaluator, %s move loop" % (
+                                      cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, args.filters, args.layers,
+                                      args.evaluator, args.loop if args.evaluator == "native" else "python"),
+                      "waves": r.get("waves"),
                       "games_per_s": args.games / dt, "expansions_per_s": r["expansions"] / dt,
                       "simulations_per_s": r["simulations"] / dt, "seconds": dt,
                       "mean_game_length": float(r["lengths"].mean()),

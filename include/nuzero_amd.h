@@ -352,6 +352,18 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
                               float* logits_dev, float* probs_dev, float* value_dev, void* stream);
 /* algorithmic FLOPs of one position (taps that fall off the board are not counted) */
 int64_t nz_boardnet_flops(const nz_boardnet* h);
+nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* policy_channels, int32_t* rows,
+                           int32_t* cols, int32_t* max_batch);
+
+/* Gamer.play_game (Training/Gamer.py:52-92) for all G SCS games of `h` to the end, tree, rules,
+ * masks AND network on the device: one simulation wave = one [expand + select] kernel followed
+ * by nz_boardnet_forward on the wave's leaves, whose count stays in device memory.  The host
+ * draws each move's random numbers (game g uses numpy RandomState(seeds_host[g]) in the
+ * reference's order) and polls for the end of the move's searches every few waves.
+ * Synchronises.  Read the games with nz_scs_search_export / nz_scs_search_status. */
+nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, void* stream);
+/* simulation waves (kernel rounds) the last nz_scs_search_play took */
+nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves);
 
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream

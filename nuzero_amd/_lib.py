@@ -113,6 +113,9 @@ SIGNATURES = {
     "nz_boardnet_set_weights": (c_int32, [c_void_p, POINTER(c_void_p), c_int32, c_int32]),
     "nz_boardnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_boardnet_flops": (c_int64, [c_void_p]),
+    "nz_boardnet_dims": (c_int32, [c_void_p] + [POINTER(c_int32)] * 5),
+    "nz_scs_search_play": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_scs_search_waves": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

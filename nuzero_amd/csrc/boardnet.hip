@@ -438,6 +438,17 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
 
 int64_t nz_boardnet_flops(const nz_boardnet* h) { return h ? h->flops : 0; }
 
+nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* policy_channels, int32_t* rows,
+                           int32_t* cols, int32_t* max_batch) {
+  if (!h) return NZ_ERR_ARG;
+  if (in_channels) *in_channels = h->net.in_channels;
+  if (policy_channels) *policy_channels = h->net.policy_channels;
+  if (rows) *rows = h->rows;
+  if (cols) *cols = h->cols;
+  if (max_batch) *max_batch = h->max_batch;
+  return NZ_OK;
+}
+
 nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
                               float* logits_dev, float* probs_dev, float* value_dev, void* stream) {
   if (!h || !images_dev || !value_dev) return NZ_ERR_ARG;

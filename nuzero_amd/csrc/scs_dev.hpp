@@ -340,4 +340,112 @@ struct Scs {
   }
 };
 
+// ---- wavefront-cooperative forms (one 64-lane wavefront per game, state and rules in LDS) ------
+// Same results as Scs::for_each_legal / Scs::state_image, spread over the lanes: lane u owns
+// unit u (SCS_MAX_UNITS <= 64), lanes stride over tiles.  All 64 lanes must call these together.
+
+// mask: MASK words in LDS, zeroed here; bit a set <=> action a is legal.
+template <int WORDS>
+__device__ __forceinline__ void scs_legal_mask_wave(const ScsRules& r, const ScsState& s, uint32_t* mask, int lane) {
+  for (int i = lane; i < WORDS; i += 64) mask[i] = 0u;
+  __syncthreads();
+  auto f = [&](int a) { atomicOr(&mask[a >> 5], 1u << (a & 31)); };
+  const Scs game(r, const_cast<ScsState&>(s));
+  const int p = s.player, S = r.stacking, T = r.tiles;
+  if (s.sub_phase == 0) {
+    const int u = game.queue_head(p, s.turn);
+    for (int t = lane; t < T; t += 64)
+      if (r.arrival[u][t] && !(s.owner[t] == (p ^ 1) || s.stack_n[t] == S)) f(t);
+  } else if (s.sub_phase == 1) {
+    const int u = lane;
+    if (u < r.n_units && r.u_player[u] == p && s.status[u] == SCS_AVAILABLE) {
+      const int t = s.tile[u], lvl = game.level_of(u);
+      f((r.confirm_limit + lvl) * T + t);
+      for (int d = 0; d < 6; ++d)
+        if (game.can_move(u, d, true)) f((r.placement_limit + d * S + lvl) * T + t);
+    }
+  } else if (s.sub_phase == 2) {
+    const int u = lane;
+    if (u < r.n_units && r.u_player[u] == p && s.status[u] == SCS_MOVED) {
+      const int t = s.tile[u];
+      f((r.no_move_limit + game.level_of(u)) * T + t);
+      for (int d = 0; d < 6; ++d) {
+        const int n = r.neighbour[t][d];
+        if (n < 0) continue;
+        for (int i = 0; i < s.stack_n[n]; ++i)
+          if (r.u_player[s.stack[n][i]] == (p ^ 1)) { f(r.movement_limit * T + n); break; }
+      }
+    }
+  } else if (lane < 6) {
+    const int n = r.neighbour[s.target][lane];
+    if (n >= 0)
+      for (int i = 0; i < s.stack_n[n]; ++i) {
+        const int u = s.stack[n][i];
+        if (r.u_player[u] != p || s.status[u] == SCS_ATTACKED) continue;
+        bool chosen = false;
+        for (int k = 0; k < s.n_attackers; ++k) chosen |= s.attackers[k] == u;
+        if (!chosen) f((r.target_limit + i) * T + n);
+      }
+    if (lane == 0 && s.n_attackers > 0) f(r.attackers_limit * T + s.target);
+  }
+  __syncthreads();
+}
+
+// img: [channels][tiles] float32 in global memory, fully written.
+__device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const ScsState& s, float* __restrict__ img, int lane) {
+  const Scs game(r, const_cast<ScsState&>(s));
+  const int T = r.tiles, S = r.stacking;
+  const int per_player = 3 * S * 3;
+  const int unit_base = 5 + 36, target_plane = unit_base + 2 * per_player, att_base = target_plane + 1,
+            phase_base = att_base + S;
+  // planes that are dense: written whole; every other plane is zero-filled first
+  for (int i = lane; i < r.channels * T; i += 64) {
+    const int c = i / T, t = i - c * T;
+    float v = 0.0f;
+    if (c < 3) v = r.terrain_f[t][c];
+    else if (c >= phase_base) {
+      const int k = c - phase_base;
+      if (k < 4) v = k == s.sub_phase ? 1.0f : 0.0f;
+      else if (k == 4) v = (float)((double)s.turn / (double)r.turns);
+      else v = s.player == 1 ? -1.0f : 1.0f;
+    }
+    img[i] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
+  for (int p = 0; p < 2; ++p)
+    if (lane < r.n_vp[p]) img[(3 + p) * T + r.vp[p][lane]] = 1.0f;
+  for (int p = 0; p < 2; ++p) {                 // the next three reinforcements of each player, schedule order
+    const bool queued = lane < r.n_units && r.u_player[lane] == p && s.status[lane] == SCS_QUEUED;
+    unsigned long long m = __ballot(queued);
+    for (int shown = 0; shown < 3 && m; ++shown) {
+      const int u = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const double importance = (double)((r.turns + 1) - (r.u_turn[u] - s.turn)) / (double)(r.turns + 1);
+      const int o = 5 + p * 18 + shown * 6;
+      for (int t = lane; t < T; t += 64) {
+        if (r.arrival[u][t]) {
+          img[o * T + t] = (float)r.u_attack[u];
+          img[(o + 1) * T + t] = (float)r.u_defense[u];
+          img[(o + 2) * T + t] = (float)s.mov[u];
+        }
+        img[(o + 3) * T + t] = img[(o + 4) * T + t] = img[(o + 5) * T + t] = (float)importance;
+      }
+    }
+  }
+  if (lane < r.n_units) {
+    const int u = lane, st = s.status[u];
+    if (st >= SCS_AVAILABLE && st <= SCS_ATTACKED) {
+      const int o = unit_base + r.u_player[u] * per_player + st * S * 3 + game.level_of(u) * 3, t = s.tile[u];
+      img[o * T + t] = (float)r.u_attack[u];
+      img[(o + 1) * T + t] = (float)r.u_defense[u];
+      img[(o + 2) * T + t] = (float)s.mov[u];
+    }
+  }
+  if (lane == 0 && s.target >= 0) img[target_plane * T + s.target] = 1.0f;
+  if (lane < s.n_attackers) {
+    const int u = s.attackers[lane];
+    if (s.status[u] != SCS_DEAD) img[(att_base + game.level_of(u)) * T + s.tile[u]] = 1.0f;
+  }
+}
+
 }  // namespace nz

@@ -63,6 +63,8 @@ struct SearchParams {
   int32_t* path_len;       // [G]
   uint32_t* leaf_mask;     // [G][MASK_WORDS] legal actions at the pending leaf
   int32_t* leaf_count;     // [1]
+  int32_t* active_count;   // [1] games that are not done with their move after a wave
+  int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
   int32_t* error_flag;
   int64_t* counters;       // [2] simulations, expansions
   // records [G][MAX_MOVES]...
@@ -145,7 +147,7 @@ __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 he
 
 __global__ void search_reset_kernel(SearchParams p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g == 0) { *p.leaf_count = 0; *p.error_flag = 0; p.counters[0] = 0; p.counters[1] = 0; }
+  if (g == 0) { *p.leaf_count = 0; *p.active_count = 0; *p.error_flag = 0; p.counters[0] = 0; p.counters[1] = 0; }
   if (g >= p.n_games) return;
   Scs(*p.rules, p.real[g]).reset();
   SNode& n = p.nodes[(size_t)g * p.cap];
@@ -193,39 +195,125 @@ __global__ void begin_move_kernel(SearchParams p, const double* __restrict__ noi
   }
 }
 
-// Simulate until the game waits on a leaf that needs an evaluation, or its simulations are used up
-// (Explorer.run_mcts, :49-61).  One wavefront per game.
-__global__ __launch_bounds__(64) void select_kernel(SearchParams p, float* __restrict__ images,
-                                                     int32_t* __restrict__ leaf_game) {
+// One simulation wave of one game, one wavefront per game (Explorer.run_mcts, :49-61):
+//   mode & 1  finish the pending expansion with the supplied evaluation (Explorer.py:162-181) and
+//             back its value up           probs [n_leaves][A] float32 post-softmax, value [n_leaves]
+//   mode & 2  simulate until the game waits on a leaf that needs an evaluation, its simulations
+//             are used up, or `budget` simulations that ended in terminal leaves have run
+// The rules, the scratch game and the legal-move mask live in LDS: the rules run on lane 0
+// (serial, latency-bound code), the children are scored, the mask and the state image are built
+// and the new children are written by all lanes.
+__global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, const float* __restrict__ probs,
+                                                   const float* __restrict__ value, float* __restrict__ images,
+                                                   int32_t* __restrict__ leaf_game) {
+  __shared__ ScsRules R;
+  __shared__ ScsState sc;
+  __shared__ uint32_t smask[MASK_WORDS];
+  __shared__ int sidx[MAXC];
+  __shared__ float sval[MAXC];
+  __shared__ float stotal;
   const int g = blockIdx.x;
   const int lane = lane_id();
-  if (p.real[g].terminal || p.pending[g] >= 0) return;
-  const ScsRules& R = *p.rules;
+  if (p.real[g].terminal) return;
+  const int A = p.rules->planes * p.rules->tiles;
   SNode* nodes = p.nodes + (size_t)g * p.cap;
   int32_t* path = p.path + (size_t)g * p.max_path;
-  ScsState& sc = p.scratch[g];
+
+  if ((mode & 1) && p.pending[g] >= 0) {
+    const int slot = p.pending[g];
+    const int plen = p.path_len[g];
+    const int leaf = path[plen - 1];
+    // legal actions in ascending order: lane w enumerates mask word w (and word 64 + w)
+    const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
+    int k = 0;
+    for (int w0 = 0; w0 < MASK_WORDS; w0 += 64) {
+      uint32_t bits = w0 + lane < MASK_WORDS ? m[w0 + lane] : 0u;
+      int inc = __popc(bits);
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      int off = k + inc - __popc(bits);
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        if (off < MAXC) sidx[off] = (w0 + lane) * 32 + b;
+        ++off;
+      }
+      k += __shfl(inc, 63, 64);
+    }
+    const int base = p.node_count[g];
+    const bool overflow = k > MAXC;
+    if (overflow || base + k > p.cap) {
+      if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
+    } else {
+      __syncthreads();
+      if (lane < k) sval[lane] = probs[(size_t)slot * A + sidx[lane]];
+      __syncthreads();
+      if (lane == 0) stotal = np_sum_sparse_f32(sidx, sval, k, 0, A);
+      __syncthreads();
+      if (stotal == 0.0f) {                 // probs += mask (Explorer.py:171-173)
+        if (lane < k) sval[lane] = sval[lane] + 1.0f;
+        __syncthreads();
+        if (lane == 0) stotal = np_sum_sparse_f32(sidx, sval, k, 0, A);
+        __syncthreads();
+      }
+      if (lane < k) {
+        SNode c;
+        c.prior = (double)(sval[lane] / stotal);
+        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)sidx[lane];
+        c.to_play = -1; c.prior_f64 = 0; c.terminal = 0; c.pad = 0;
+        nodes[base + lane] = c;
+      }
+      if (lane == 0) {
+        nodes[leaf].child_base = base;
+        nodes[leaf].n_children = (uint16_t)k;
+        p.node_count[g] = base + k;
+      }
+    }
+    if (lane == 0) {
+      p.pending[g] = -1;
+      p.sims_left[g] -= 1;
+      atomicAdd((unsigned long long*)&p.counters[0], 1ull);
+      atomicAdd((unsigned long long*)&p.counters[1], 1ull);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const double v = (double)value[slot];
+    for (int i = lane; i < plen; i += 64) {
+      SNode& n = nodes[path[i]];
+      n.visit += 1;
+      n.value_sum = n.value_sum + v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (!(mode & 2) || p.pending[g] >= 0) return;
   int sims_left = p.sims_left[g];
+  if (sims_left <= 0) return;
+
+  {
+    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&R);
+    for (int i = lane; i < (int)(sizeof(ScsRules) / 4); i += 64) dst[i] = src[i];
+  }
   const int root = p.root[g];
   long n_sim = 0;
+  int budget = p.terminal_budget;
+  bool queued = false;
 
-  while (sims_left > 0) {
-    // scratch_game = game.shallow_clone()
-    {
-      const int words = (int)(sizeof(ScsState) / 4);
+  while (sims_left > 0 && budget > 0) {
+    {   // scratch_game = game.shallow_clone()
       const uint32_t* src = reinterpret_cast<const uint32_t*>(&p.real[g]);
       uint32_t* dst = reinterpret_cast<uint32_t*>(&sc);
-      for (int i = lane; i < words; i += 64) dst[i] = src[i];
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) dst[i] = src[i];
+      __syncthreads();
     }
     int node = root, plen = 1;
     if (lane == 0) path[0] = root;
+    bool bad = false;
     while (nodes[node].n_children > 0) {
       const SNode parent = nodes[node];
-      if (parent.visit >= p.tab_len || plen >= p.max_path) {
-        if (lane == 0) atomicOr(p.error_flag, 2);
-        sims_left = 0;
-        break;
-      }
+      if (parent.visit >= p.tab_len || plen >= p.max_path) { bad = true; break; }
       const double sq = p.sqrt_tab[parent.visit], cb = p.bias_tab[parent.visit];
       const bool negate = parent.to_play == p.negate_player;
       double score = -INFINITY;
@@ -247,9 +335,13 @@ __global__ __launch_bounds__(64) void select_kernel(SearchParams p, float* __res
         path[plen] = node;
       }
       ++plen;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    if (sims_left == 0) break;
+    if (bad) {
+      if (lane == 0) atomicOr(p.error_flag, 2);
+      sims_left = 0;
+      break;
+    }
+    __syncthreads();                          // lane 0's steps on the scratch game are visible to every lane
     // evaluate (Explorer.py:137-181)
     const int to_play = sc.player, term = sc.terminal;
     if (term) {
@@ -257,14 +349,16 @@ __global__ __launch_bounds__(64) void select_kernel(SearchParams p, float* __res
         nodes[node].to_play = (int8_t)to_play;
         nodes[node].terminal = 1;
       }
-      const double value = (double)sc.terminal_value;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const double v = (double)sc.terminal_value;
       for (int i = lane; i < plen; i += 64) {
         SNode& n = nodes[path[i]];
         n.visit += 1;
-        n.value_sum = n.value_sum + value;
+        n.value_sum = n.value_sum + v;
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       --sims_left;
+      --budget;
       ++n_sim;
       continue;
     }
@@ -276,80 +370,29 @@ __global__ __launch_bounds__(64) void select_kernel(SearchParams p, float* __res
       p.pending[g] = slot;
       p.path_len[g] = plen;
       nodes[node].to_play = (int8_t)to_play;
-      uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
-      for (int i = 0; i < MASK_WORDS; ++i) m[i] = 0u;
-      Scs(R, sc).for_each_legal([&](int a) { m[a >> 5] |= 1u << (a & 31); });
-      Scs(R, sc).state_image(images + (size_t)slot * R.channels * R.tiles);
     }
+    slot = __shfl(slot, 0, 64);
+    scs_legal_mask_wave<MASK_WORDS>(R, sc, smask, lane);
+    uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
+    for (int i = lane; i < MASK_WORDS; i += 64) m[i] = smask[i];
+    scs_state_image_wave(R, sc, images + (size_t)slot * R.channels * R.tiles, lane);
+    queued = true;
     break;
   }
   if (lane == 0) {
     p.sims_left[g] = sims_left;
     if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)n_sim);
+    if (queued || sims_left > 0) atomicAdd(p.active_count, 1);
   }
 }
 
-// Finish the pending expansions with the supplied evaluations (Explorer.py:162-181) and back up.
-// probs: [n_leaves][num_actions] float32 post-softmax, value: [n_leaves] float32.
-__global__ __launch_bounds__(64) void expand_kernel(SearchParams p, const float* __restrict__ probs,
-                                                     const float* __restrict__ value) {
-  const int g = blockIdx.x;
-  const int lane = lane_id();
-  const int slot = p.pending[g];
-  if (slot < 0) return;
-  const ScsRules& R = *p.rules;
-  const int A = R.planes * R.tiles;
-  SNode* nodes = p.nodes + (size_t)g * p.cap;
-  const int32_t* path = p.path + (size_t)g * p.max_path;
-  const int plen = p.path_len[g];
-  const int leaf = path[plen - 1];
-  if (lane == 0) {
-    // legal actions ascending
-    int idx[MAXC];
-    float val[MAXC];
-    int k = 0;
-    bool overflow = false;
-    const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
-    for (int w = 0; w < MASK_WORDS; ++w) {
-      uint32_t bits = m[w];
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        if (k < MAXC) { idx[k] = w * 32 + b; val[k] = probs[(size_t)slot * A + idx[k]]; ++k; }
-        else overflow = true;
-      }
-    }
-    const int base = p.node_count[g];
-    if (overflow || base + k > p.cap) {
-      atomicOr(p.error_flag, overflow ? 16 : 1);
-    } else {
-      float total = np_sum_sparse_f32(idx, val, k, 0, A);
-      if (total == 0.0f) {              // probs += mask
-        for (int i = 0; i < k; ++i) val[i] = val[i] + 1.0f;
-        total = np_sum_sparse_f32(idx, val, k, 0, A);
-      }
-      for (int i = 0; i < k; ++i) {
-        SNode& c = nodes[base + i];
-        c.prior = (double)(val[i] / total);
-        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)idx[i];
-        c.to_play = -1; c.prior_f64 = 0; c.terminal = 0; c.pad = 0;
-      }
-      nodes[leaf].child_base = base;
-      nodes[leaf].n_children = (uint16_t)k;
-      p.node_count[g] = base + k;
-    }
-    p.pending[g] = -1;
-    p.sims_left[g] -= 1;
-    atomicAdd((unsigned long long*)&p.counters[0], 1ull);
-    atomicAdd((unsigned long long*)&p.counters[1], 1ull);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  const double v = (double)value[slot];
-  for (int i = lane; i < plen; i += 64) {
-    SNode& n = nodes[path[i]];
-    n.visit += 1;
-    n.value_sum = n.value_sum + v;
-  }
+__global__ void search_status_kernel(SearchParams p, int32_t* out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  const ScsState& s = p.real[g];
+  int32_t* o = out + g * 7;
+  o[0] = s.player; o[1] = s.sub_phase; o[2] = s.stage; o[3] = s.turn; o[4] = s.terminal; o[5] = s.terminal_value;
+  o[6] = s.length;
 }
 
 // select_action, records, step and re-rooting (Explorer.py:70-97,183-199; Gamer.py:71-79)
@@ -430,6 +473,11 @@ struct nz_scs_search {
   SearchParams p;
   std::vector<void*> allocs;
   std::string error;
+  // nz_scs_search_play: leaf batch, evaluations and the host-drawn randomness of one move
+  float *images = nullptr, *probs = nullptr, *value = nullptr;
+  int32_t *leaf_game = nullptr, *nchild = nullptr, *status = nullptr;
+  double *noise = nullptr, *uniforms = nullptr;
+  int64_t waves = 0;
 };
 
 namespace {
@@ -498,6 +546,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.negate_player = 2;                       // Explorer.py:124; SCS players are 0 and 1
   p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
   p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
+  p.terminal_budget = 1 << 30;
   p.frac = cfg->root_exploration_fraction;
   p.one_minus_frac = 1.0 - cfg->root_exploration_fraction;
   p.value_factor = cfg->value_factor;
@@ -509,7 +558,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   bool ok = dalloc(h, &rules, 1) && dalloc(h, &p.real, G) && dalloc(h, &p.scratch, G) &&
             dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
             dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
-            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 1) &&
+            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 2) &&
             dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 2) && dalloc(h, &bias, (size_t)p.tab_len) &&
             dalloc(h, &sq, (size_t)p.tab_len) && dalloc(h, &p.rec_action, GM) && dalloc(h, &p.rec_tree_size, GM) &&
             dalloc(h, &p.rec_children, GM) && dalloc(h, &p.rec_bias, GM) && dalloc(h, &p.rec_root_value_sum, GM) &&
@@ -527,6 +576,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
     nz_scs_search_destroy(h);
     return sfail(nullptr, NZ_ERR_HIP, "upload failed");
   }
+  p.active_count = p.leaf_count + 1;
   p.rules = rules;
   p.bias_tab = bias;
   p.sqrt_tab = sq;
@@ -574,8 +624,10 @@ nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* lea
   if (!h || !images_dev || !leaf_game_dev || !n_leaves_host) return NZ_ERR_ARG;
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(select_kernel, dim3(h->n_games), dim3(64), 0, s, h->p, images_dev, leaf_game_dev);
+  S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
+  h->p.terminal_budget = 1 << 30;             // run on until a leaf needs an evaluation, as this API promises
+  hipLaunchKernelGGL(wave_kernel, dim3(h->n_games), dim3(64), 0, s, h->p, 2, (const float*)nullptr, (const float*)nullptr,
+                     images_dev, leaf_game_dev);
   S_HIP(h, hipGetLastError());
   S_HIP(h, hipMemcpyAsync(n_leaves_host, h->p.leaf_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   S_HIP(h, hipStreamSynchronize(s));
@@ -585,7 +637,8 @@ nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* lea
 nz_status nz_scs_search_expand(nz_scs_search* h, const float* probs_dev, const float* value_dev, void* stream) {
   if (!h || !probs_dev || !value_dev) return NZ_ERR_ARG;
   S_HIP(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(expand_kernel, dim3(h->n_games), dim3(64), 0, (hipStream_t)stream, h->p, probs_dev, value_dev);
+  hipLaunchKernelGGL(wave_kernel, dim3(h->n_games), dim3(64), 0, (hipStream_t)stream, h->p, 1, probs_dev, value_dev,
+                     (float*)nullptr, (int32_t*)nullptr);
   S_HIP(h, hipGetLastError());
   return NZ_OK;
 }
@@ -601,6 +654,102 @@ nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, v
 }
 
 nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream);
+
+// Gamer.play_game for all games to the end with the network on the device too: the move loop of
+// Training/Gamer.py:52-92 and Explorer.run_mcts, one simulation wave = [expand + select] kernel
+// -> nz_boardnet_forward on the wave's leaves (batch size read from device memory).  The host
+// only draws each move's random numbers (numpy RandomState streams, one per game, in the
+// reference's order) and checks every few waves whether the move's searches are complete.
+nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, void* stream) {
+  if (!h || !net || (h->cfg.training && !seeds_host)) return sfail(h, NZ_ERR_ARG, "null argument");
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int G = h->n_games;
+  const ScsRules& R = h->host_rules;
+  const int A = R.planes * R.tiles;
+  int32_t nin = 0, npol = 0, nrows = 0, ncols = 0, nmax = 0;
+  if (nz_boardnet_dims(net, &nin, &npol, &nrows, &ncols, &nmax) != NZ_OK) return sfail(h, NZ_ERR_ARG, "bad network handle");
+  if (nin != R.channels || npol != R.planes || nrows != R.rows || ncols != R.cols)
+    return sfail(h, NZ_ERR_ARG, "network is %d planes -> %d planes on %dx%d, the game needs %d -> %d on %dx%d", nin, npol,
+                 nrows, ncols, R.channels, R.planes, R.rows, R.cols);
+  if (nmax < G) return sfail(h, NZ_ERR_ARG, "network max_batch %d < %d games", nmax, G);
+  if (!h->images) {
+    const bool ok = dalloc(h, &h->images, (size_t)G * R.channels * R.tiles) && dalloc(h, &h->probs, (size_t)G * A) &&
+                    dalloc(h, &h->value, (size_t)G) && dalloc(h, &h->leaf_game, (size_t)G) &&
+                    dalloc(h, &h->nchild, (size_t)G) && dalloc(h, &h->status, (size_t)G * 7) &&
+                    dalloc(h, &h->noise, (size_t)G * MAXC) && dalloc(h, &h->uniforms, (size_t)G * 3);
+    if (!ok) return sfail(h, NZ_ERR_HIP, "device allocation failed");
+  }
+  std::vector<nz_rng*> rngs;
+  struct RngGuard {
+    std::vector<nz_rng*>& v;
+    ~RngGuard() { for (nz_rng* r : v) nz_rng_destroy(r); }
+  } guard{rngs};
+  if (h->cfg.training)
+    for (int g = 0; g < G; ++g) rngs.push_back(nz_rng_create(seeds_host[g]));
+  std::vector<int32_t> status((size_t)G * 7), nchild(G);
+  std::vector<double> noise((size_t)G * MAXC), uni((size_t)G * 3);
+  nz_status st = nz_scs_search_reset(h, stream);
+  if (st != NZ_OK) return st;
+  h->waves = 0;
+  const dim3 grid1((G + 127) / 128), block1(128);
+  for (int move = 0; move < MAX_MOVES; ++move) {
+    hipLaunchKernelGGL(search_status_kernel, grid1, block1, 0, s, h->p, h->status);
+    if (h->cfg.training) hipLaunchKernelGGL(root_children_kernel, grid1, block1, 0, s, h->p, h->nchild);
+    S_HIP(h, hipMemcpyAsync(status.data(), h->status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (h->cfg.training)
+      S_HIP(h, hipMemcpyAsync(nchild.data(), h->nchild, nchild.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    S_HIP(h, hipStreamSynchronize(s));
+    bool any = false;
+    for (int g = 0; g < G; ++g) any |= status[(size_t)g * 7 + 4] == 0;
+    if (!any) break;
+    if (h->cfg.training) {
+      std::fill(noise.begin(), noise.end(), 0.0);
+      std::fill(uni.begin(), uni.end(), 0.0);
+      for (int g = 0; g < G; ++g) {
+        if (status[(size_t)g * 7 + 4]) continue;
+        nz_rng* r = rngs[g];
+        nz_rng_gamma(r, h->cfg.root_dist_alpha, h->cfg.root_dist_beta, nchild[g], &noise[(size_t)g * MAXC]);
+        double* u = &uni[(size_t)g * 3];
+        if (status[(size_t)g * 7 + 6] < h->cfg.number_of_softmax_moves) {
+          u[2] = nz_rng_double(r);
+        } else {
+          u[0] = nz_rng_double(r);
+          u[1] = nz_rng_double(r);
+          if (u[0] < h->cfg.epsilon_softmax_exploration || u[1] < h->cfg.epsilon_random_exploration) u[2] = nz_rng_double(r);
+        }
+      }
+      S_HIP(h, hipMemcpyAsync(h->noise, noise.data(), noise.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      S_HIP(h, hipMemcpyAsync(h->uniforms, uni.data(), uni.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    hipLaunchKernelGGL(begin_move_kernel, dim3(G), dim3(64), 0, s, h->p, h->noise);
+    h->p.terminal_budget = 16;
+    const int sims = h->cfg.mcts_simulations;
+    for (int w = 0;; ++w) {
+      S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
+      hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, h->images, h->leaf_game);
+      ++h->waves;
+      if ((w & 7) == 7 || w >= sims - 1) {
+        int32_t active = 0;
+        S_HIP(h, hipMemcpyAsync(&active, h->p.active_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        S_HIP(h, hipStreamSynchronize(s));
+        if (active == 0) break;
+        if (w > sims + 2) return sfail(h, NZ_ERR_STATE, "internal: a move's searches did not finish in %d waves", w);
+      }
+      if (nz_boardnet_forward(net, h->images, G, h->p.leaf_count, nullptr, h->probs, h->value, stream) != NZ_OK)
+        return sfail(h, NZ_ERR_HIP, "network: %s", nz_boardnet_last_error(net));
+    }
+    st = nz_scs_search_end_move(h, h->uniforms, stream);
+    if (st != NZ_OK) return st;
+  }
+  return NZ_OK;
+}
+
+nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves) {
+  if (!h || !waves) return NZ_ERR_ARG;
+  *waves = h->waves;
+  return NZ_OK;
+}
 
 nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
                                double* bias, double* root_value_sum, int32_t* child_action, int32_t* child_visit,
@@ -626,16 +775,6 @@ nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree
 
 }  // extern "C"
 
-namespace {
-__global__ void search_status_kernel(SearchParams p, int32_t* out) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= p.n_games) return;
-  const ScsState& s = p.real[g];
-  int32_t* o = out + g * 7;
-  o[0] = s.player; o[1] = s.sub_phase; o[2] = s.stage; o[3] = s.turn; o[4] = s.terminal; o[5] = s.terminal_value;
-  o[6] = s.length;
-}
-}  // namespace
 
 extern "C" nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream) {
   if (!h || !status_dev) return NZ_ERR_ARG;

@@ -242,6 +242,20 @@ class ScsSelfPlay:
             self._check(lib.nz_scs_search_end_move(self._h, c_void_p(uni_d.data_ptr()), self._stream()))
         return self.export()
 
+    def play_native(self, net, seeds):
+        """As play(), with the network on the device as well (`net`: nuzero_amd.boardnet.BoardNet with
+        max_batch >= n_games): the whole move loop runs in the library (nz_scs_search_play), the
+        host only draws the per-move random numbers.  Same games as play(net.evaluator(), seeds)."""
+        seeds = np.ascontiguousarray(np.asarray(list(seeds), dtype=np.uint32))
+        assert seeds.shape == (self.n_games,)
+        self._check(lib.nz_scs_search_play(self._h, net._h, c_void_p(seeds.ctypes.data), self._stream()))
+        out = self.export()
+        self.evaluations = out["expansions"]
+        waves = ctypes.c_int64(0)
+        self._check(lib.nz_scs_search_waves(self._h, byref(waves)))
+        out["waves"] = int(waves.value)
+        return out
+
     def export(self):
         G, M, C = self.n_games, self.MAX_MOVES, self.MAX_CHILDREN
         dev = self.device

@@ -135,3 +135,41 @@ def test_scs_selfplay_with_the_native_network():
     assert r["expansions"] == sp.evaluations
     sp.close()
     net.close()
+
+
+def test_native_move_loop_plays_the_same_games_as_the_lockstep_api():
+    """nz_scs_search_play (move loop in the library, leaf count on the device, terminal-simulation
+    budget per wave) against ScsSelfPlay.play driving the same kernels wave by wave from Python:
+    identical roots, visit counts, priors and value sums for every move of every game."""
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scs_configs", "late_reinforcements_5x5.yml")
+    cfg = ScsGameConfig(path)
+    w = synthetic_weights(9, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 2), 2.0)
+    net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=2, max_batch=24)
+    net.set_weights(w)
+    search = {"Simulation": {"mcts_simulations": 40, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 6, "epsilon_softmax_exploration": 0.1,
+                              "epsilon_random_exploration": 0.05, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.25,
+                              "root_dist_alpha": 0.3, "root_dist_beta": 1}}
+    seeds = list(range(500, 524))
+    a = ScsSelfPlay(cfg, search, 24)
+    ra = a.play(net.evaluator(), seeds)
+    b = ScsSelfPlay(cfg, search, 24)
+    rb = b.play_native(net, seeds)
+    assert (ra["lengths"] > 10).all()
+    for k in ("lengths", "outcomes", "actions", "tree_size", "n_children"):
+        assert np.array_equal(ra[k], rb[k]), k
+    for g in range(24):                       # records past a game's end / a root's children are not defined
+        n = ra["lengths"][g]
+        for k in ("bias", "root_value_sum"):
+            assert np.array_equal(ra[k][g, :n], rb[k][g, :n]), (k, g)
+        for m in range(n):
+            c = ra["n_children"][g, m]
+            for k in ("child_action", "child_visit", "child_prior", "child_value_sum"):
+                assert np.array_equal(ra[k][g, m, :c], rb[k][g, m, :c]), (k, g, m)
+    assert ra["expansions"] == rb["expansions"] and ra["simulations"] == rb["simulations"]
+    assert rb["waves"] > 0
+    a.close(); b.close(); net.close()
