@@ -4,13 +4,16 @@
 //
 // The fused whole-network kernel of net_dev.hpp keeps a 3x3 board's activations in LDS; a 10x10
 // board with 256 filters does not fit, so here every convolution is its own launch and the
-// activations live in HBM/L2 in position-major, channel-minor order ("NHWC": row = position *
-// H*W + cell, channels contiguous and padded to a multiple of 16).  A convolution is an implicit
+// activations live in HBM/L2 as rows of channels (contiguous, padded to a multiple of 16).  Row
+// order: positions in groups of 16, row = (group * H*W + cell) * 16 + position-in-group, so the
+// 16 rows of one MFMA tile are ONE board cell of 16 positions.  A convolution is an implicit
 // GEMM on the FP32 matrix cores: rows = board cells of all positions, K = 9 taps x input
 // channels, columns = output channels.
+//   * a tap that falls off the board (zero 'same' padding, RecurrentNet.py:47-52) does so for
+//     the whole tile, so it is skipped: the MFMAs executed are exactly the algorithmic ones
+//     (169 of 225 (cell, tap) pairs on a 5x5 board);
 //   * A operand (activations): lane (row r = lane & 15, k-quarter q = lane >> 4) loads the four
-//     channels 16 kg + 4 q .. + 3 of the tap's neighbour cell as one 16-byte load; a tap that
-//     falls off the board contributes zeros (zero 'same' padding, RecurrentNet.py:47-52).
+//     channels 16 kg + 4 q .. + 3 of the tap's neighbour cell as one 16-byte load;
 //   * B operand (weights): packed on the host per (column tile, tap, channel group) in exactly
 //     the per-lane order v_mfma_f32_16x16x4_f32 wants, so one coalesced 16-byte load per lane.
 //   * one wavefront owns MT x 16 rows and NT x 16 output channels; a workgroup is 4 wavefronts
@@ -28,6 +31,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgs {
   const float* src0;     // [rows][c0] NHWC, c0 a multiple of 16
   const float* src1;     // second K source (recall concat) or nullptr
-  const float* w;        // packed [ntile][tap][kg0 + kg1][64 lanes][4]
+  const float* w;        // packed [ntile][10 taps][kg0 + kg1][64 lanes][4]
   const float* res;      // residual [rows][cd] or nullptr
   float* dst;            // [rows][cd]
   const int32_t* n_dev;  // live positions on the device (nullptr: n_host)
@@ -60,91 +64,125 @@ __device__ __forceinline__ float activate(float v, int act) {
   }
 }
 
-template <int MT, int NT>
+// K steps in flight per wavefront: the loads of step i + DEPTH are issued before the MFMAs of step i.
+template <int MT, int NT, int DEPTH>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n_pos = p.n_dev ? *p.n_dev : p.n_host;
-  const int M = n_pos * p.hw;
-  const int m0 = (blockIdx.x * 4 + wave) * 16 * MT;
-  if (m0 >= M) return;                               // whole wavefront out of range (uniform)
+  const int n_groups = (n_pos + 15) >> 4;
+  // one wavefront: board cell `cell` of the position groups g0 .. g0 + MT - 1
+  const int task = blockIdx.x * 4 + wave;
+  const int cell = task % p.hw, g0 = (task / p.hw) * MT;
+  if (g0 >= n_groups) return;                        // uniform per wavefront
   const int nt0 = blockIdx.y * NT;
   const int kg0 = p.c0 >> 4, kg1 = p.src1 ? (p.c1 >> 4) : 0, kgt = kg0 + kg1;
 
-  int row[MT], cy[MT], cx[MT];
+  uint32_t vmask = 0;                                // taps that stay on the board for this cell
+  {
+    const int cy = cell / p.wd, cx = cell % p.wd;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int y = cy + tap / 3 - 1, x = cx + tap % 3 - 1;
+      if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.wd) vmask |= 1u << tap;
+    }
+  }
+  int row[MT];
+  bool live[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    row[m] = m0 + m * 16 + (lane & 15);
-    const int cell = row[m] % p.hw;
-    cy[m] = row[m] < M ? cell / p.wd : -4;            // rows past the end never match a tap
-    cx[m] = cell % p.wd;
+    live[m] = g0 + m < n_groups;
+    row[m] = ((g0 + m) * p.hw + cell) * 16 + (lane & 15);
   }
+
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const size_t tile_stride = (size_t)9 * kgt * 256;    // floats per column tile
+  // packed weights: [column tile][10 taps][kgt][64 lanes][4]; "tap 9" is a block of zeros that the
+  // steps past the end of the K loop read, so the pipeline needs no conditional loads
+  const size_t tile_stride = (size_t)10 * kgt * 256;
   const float* wbase = p.w + (size_t)nt0 * tile_stride + lane * 4;
   const int q4 = (lane >> 4) * 4;
 
-  for (int tap = 0; tap < 9; ++tap) {
-    const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-    int nbr[MT];
-    bool any = false;
+  const int total = __popc(vmask) * kgt;
+  const int rounds = (total + DEPTH - 1) / DEPTH;
+  uint32_t taps_left = vmask;
+  int tap = __ffs(taps_left) - 1, kg = 0;            // the centre tap is always on the board
+  taps_left &= taps_left - 1;
+
+  f32x4 a[DEPTH][MT], b[DEPTH][NT];
+  auto issue = [&](int d) {
+#ifdef NZ_ABLATE_CONV_NOLOAD       // timing experiment: no memory operands at all
+    {
+      const float f = (float)(kg + tap);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[d][m] = f32x4{f, f, f, f};
+#pragma unroll
+      for (int n = 0; n < NT; ++n) b[d][n] = f32x4{f, f, f, f};
+      if (++kg == kgt) {
+        kg = 0;
+        if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
+        else tap = 9;
+      }
+      return;
+    }
+#endif
+    const int shift = ((tap / 3 - 1) * p.wd + (tap % 3 - 1)) * 16;
+    const bool second = kg >= kg0;
+    const float* src = second ? p.src1 : p.src0;
+    const int cs = second ? p.s1 : p.s0;
+    const int ch = (second ? kg - kg0 : kg) * 16 + q4;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const bool ok = (unsigned)(cy[m] + dy) < (unsigned)p.h && (unsigned)(cx[m] + dx) < (unsigned)p.wd;
-      nbr[m] = ok ? row[m] + dy * p.wd + dx : -1;
-      any |= ok;
+#ifdef NZ_ABLATE_CONV_A            // timing experiment: every activation load hits the same rows
+      if (live[m] && tap < 9) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)row[m] * cs + q4);
+#else
+      if (live[m] && tap < 9) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)(row[m] + shift) * cs + ch);
+#endif
+      else a[d][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (!__any(any)) continue;                        // the whole tile is off the board for this tap
-    const float* wt = wbase + (size_t)tap * kgt * 256;
-    for (int src = 0; src < 2; ++src) {
-      const float* s = src ? p.src1 : p.src0;
-      const int cs = src ? p.s1 : p.s0;
-      const int kgn = src ? kg1 : kg0;
-      const float* wk = wt + (size_t)(src ? kg0 : 0) * 256;
-      if (kgn == 0) continue;
-      f32x4 a[2][MT], b[2][NT];
-      auto load = [&](int buf, int kg) {
+#ifdef NZ_ABLATE_CONV_B            // timing experiment: every weight load hits the same line
+    const float* wk = wbase;
+#else
+    const float* wk = wbase + ((size_t)tap * kgt + kg) * 256;
+#endif
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          if (nbr[m] >= 0) a[buf][m] = *reinterpret_cast<const f32x4*>(s + (size_t)nbr[m] * cs + kg * 16 + q4);
-          else a[buf][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int n = 0; n < NT; ++n) b[d][n] = *reinterpret_cast<const f32x4*>(wk + n * tile_stride);
+    if (++kg == kgt) {
+      kg = 0;
+      if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
+      else tap = 9;
+    }
+  };
+  auto mac = [&](int d) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) b[buf][n] = *reinterpret_cast<const f32x4*>(wk + n * tile_stride + (size_t)kg * 256);
-      };
-      auto mac = [&](int buf) {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][m][j], b[d][n][j], acc[m][n], 0, 0, 0);
+  };
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-              acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[buf][m][j], b[buf][n][j], acc[m][n], 0, 0, 0);
-      };
-      load(0, 0);
-      int kg = 0;
-      for (; kg + 2 <= kgn; kg += 2) {                // ping-pong: the next group's loads fly under the MFMAs
-        load(1, kg + 1);
-        mac(0);
-        if (kg + 2 < kgn) load(0, kg + 2);
-        mac(1);
-      }
-      if (kg < kgn) mac(0);
+  for (int d = 0; d < DEPTH; ++d) issue(d);
+  for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      mac(d);
+      issue(d);
     }
   }
 
   const int col = lane & 15, r4 = (lane >> 4) * 4;
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+  for (int m = 0; m < MT; ++m) {
+    if (!live[m]) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int orow = m0 + m * 16 + r4 + r;
-      if (orow >= M) continue;
+      const int orow = ((g0 + m) * p.hw + cell) * 16 + r4 + r;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         const size_t o = (size_t)orow * p.cd + (nt0 + n) * 16 + col;
@@ -153,19 +191,24 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
         p.dst[o] = activate(v, p.act);
       }
     }
+  }
 }
 
-// [n][C][H*W] (what Game.generate_network_input stacks) -> [n * H*W][cp], channels zero-padded.
+__device__ __forceinline__ size_t row_of(size_t n, int cell, int hw) { return ((n >> 4) * hw + cell) * 16 + (n & 15); }
+
+// [n][C][H*W] (what Game.generate_network_input stacks) -> rows of cp channels, zero-padded in the
+// channels and in the positions that fill up the last group of 16.
 __global__ void nchw_to_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* n_dev,
                                     int n_host, int c, int cp, int hw) {
   const int n_pos = n_dev ? *n_dev : n_host;
-  const size_t total = (size_t)n_pos * hw * cp;
+  const size_t n_pad = (size_t)((n_pos + 15) & ~15);
+  const size_t total = n_pad * hw * cp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int ch = (int)(i % cp);
-    const size_t r = i / cp;
-    const int cell = (int)(r % hw);
-    const size_t n = r / hw;
-    out[i] = ch < c ? in[(n * c + ch) * hw + cell] : 0.f;
+    const size_t r = i / cp;                       // output row
+    const size_t n = (r >> 4) / hw * 16 + (r & 15);
+    const int cell = (int)((r >> 4) % hw);
+    out[i] = (ch < c && n < (size_t)n_pos) ? in[(n * c + ch) * hw + cell] : 0.f;
   }
 }
 
@@ -181,10 +224,9 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
   if (n >= n_pos) return;
   const int lane = threadIdx.x;
   const int A = planes * hw;
-  const float* pr = pol + (size_t)n * hw * pp;
   float mx = -INFINITY;
   for (int a = lane; a < A; a += 64) {
-    const float v = pr[(a % hw) * pp + a / hw];
+    const float v = pol[row_of(n, a % hw, hw) * pp + a / hw];
     if (logits) logits[(size_t)n * A + a] = v;
     mx = fmaxf(mx, v);
   }
@@ -192,7 +234,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
   if (probs) {
     float sum = 0.f;
     for (int a = lane; a < A; a += 64) {
-      const float e = expf(pr[(a % hw) * pp + a / hw] - mx);
+      const float e = expf(pol[row_of(n, a % hw, hw) * pp + a / hw] - mx);
       probs[(size_t)n * A + a] = e;
       sum += e;
     }
@@ -200,7 +242,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
     for (int a = lane; a < A; a += 64) probs[(size_t)n * A + a] /= sum;
   }
   float s = 0.f;
-  for (int c = lane; c < hw; c += 64) s += val[((size_t)n * hw + c) * vp];
+  for (int c = lane; c < hw; c += 64) s += val[row_of(n, c, hw) * vp];
   for (int o = 32; o; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) value[n] = tanhf(s / (float)hw);
 }
@@ -266,7 +308,7 @@ bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c
   PackedConv pc;
   pc.cout = cout; pc.coutp = pad16(cout); pc.cin = c0 + c1; pc.c0p = c0p; pc.c1p = c1p;
   const int ntiles = pc.coutp / 16, kgt = (c0p + c1p) / 16;
-  std::vector<float> host((size_t)ntiles * 9 * kgt * 256, 0.f);
+  std::vector<float> host((size_t)ntiles * 10 * kgt * 256, 0.f);      // tap 9: zeros (see conv_kernel)
   std::vector<float> wh((size_t)cout * (c0 + c1) * k * k);
   if (hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return false;
   for (int nt = 0; nt < ntiles; ++nt)
@@ -282,7 +324,7 @@ bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c
             if (ch < c0p) cin_idx = ch < c0 ? ch : -1;
             else { ch -= c0p; cin_idx = ch < c1 ? c0 + ch : -1; }
             if (co >= cout || cin_idx < 0) continue;
-            host[(((size_t)nt * 9 + tap) * kgt + kg) * 256 + lane * 4 + j] =
+            host[(((size_t)nt * 10 + tap) * kgt + kg) * 256 + lane * 4 + j] =
                 wh[((size_t)co * (c0 + c1) + cin_idx) * k * k + wt];
           }
     }
@@ -295,20 +337,33 @@ bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c
   return true;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int DEPTH>
 void launch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
-  const int rows_max = a.n_host * a.hw;
-  dim3 grid((rows_max + 64 * MT - 1) / (64 * MT), ntiles / NT);
-  hipLaunchKernelGGL((conv_kernel<MT, NT>), grid, dim3(256), 0, s, a);
+  const int groups = (a.n_host + 15) / 16;
+  const int tasks = (groups + MT - 1) / MT * a.hw;           // wavefronts: one board cell of MT position groups
+  dim3 grid((tasks + 3) / 4, ntiles / NT);
+  hipLaunchKernelGGL((conv_kernel<MT, NT, DEPTH>), grid, dim3(256), 0, s, a);
 }
 
+// Tile shape per layer: NT = as many 16-column tiles as divide the layer's width (up to 4), so
+// the activation fragment is reused NT times; MT = 2 position groups per wavefront for wide
+// layers once there are enough positions to keep every SIMD busy anyway.  Measured alternatives
+// (MT = 4; weight fragments shared through LDS by the four wavefronts of a workgroup; operand
+// ablations) are in profiles/r01_boardnet_tiles.txt.
 void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
-  const bool big = (int64_t)a.n_host * a.hw >= 64 * 2 * 256;     // enough rows to fill 256 CUs with 32-row tiles
-  int nt = ntiles % 4 == 0 ? 4 : ntiles % 3 == 0 ? 3 : ntiles % 2 == 0 ? 2 : 1;
-#define CASE(MTV, NTV) launch_conv<MTV, NTV>(a, ntiles, s)
-  if (big) { if (nt == 4) CASE(2, 4); else if (nt == 3) CASE(2, 3); else if (nt == 2) CASE(2, 2); else CASE(2, 1); }
-  else { if (nt == 4) CASE(1, 4); else if (nt == 3) CASE(1, 3); else if (nt == 2) CASE(1, 2); else CASE(1, 1); }
-#undef CASE
+  static const int force_mt = getenv("NZ_BOARDNET_MT") ? atoi(getenv("NZ_BOARDNET_MT")) : 0;   // tuning experiments
+  const int kgt = (a.c0 + a.c1) / 16;
+  if (ntiles % 4 == 0) {
+    const int mt = force_mt ? force_mt : (a.n_host >= 1024 && kgt >= 8) ? 2 : 1;
+    if (mt == 2) launch_conv<2, 4, 3>(a, ntiles, s);
+    else launch_conv<1, 4, 4>(a, ntiles, s);
+  } else if (ntiles % 3 == 0) {
+    launch_conv<1, 3, 4>(a, ntiles, s);
+  } else if (ntiles % 2 == 0) {
+    launch_conv<1, 2, 4>(a, ntiles, s);
+  } else {
+    launch_conv<1, 1, 4>(a, ntiles, s);
+  }
 }
 }  // namespace
 
@@ -351,7 +406,7 @@ nz_status nz_boardnet_create(nz_boardnet** out, const nz_net_desc* net, int32_t 
   h->buffer_channels = {h->inp, h->widthp, h->widthp, h->widthp, pad16(pc[1]), pad16(pc[2]), vmax, vmax};
   for (int c : h->buffer_channels) {
     float* b = nullptr;
-    const size_t n = (size_t)max_batch * h->hw * c;
+    const size_t n = (size_t)((max_batch + 15) / 16 * 16) * h->hw * c;
     if (hipMalloc((void**)&b, n * sizeof(float)) != hipSuccess || hipMemset(b, 0, n * sizeof(float)) != hipSuccess) {
       nz_boardnet_destroy(h);
       return bfail(nullptr, NZ_ERR_HIP, "device allocation failed");
@@ -457,7 +512,7 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
   if (n == 0) return NZ_OK;
   B_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  const size_t total = (size_t)n * h->hw * h->inp;
+  const size_t total = (size_t)((n + 15) / 16 * 16) * h->hw * h->inp;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
                      h->net.in_channels, h->inp, h->hw);

@@ -448,4 +448,99 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
   }
 }
 
+// Scs::step by a whole wavefront: lane 0 applies the action (a handful of stores), the turn
+// machine's "is any unit of player p queued / available / moved" scans (update_game_env,
+// :687-831) become one ballot each instead of a loop over the units.
+__device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, int action, int lane) {
+  Scs game(r, s);
+  const int T = r.tiles, S = r.stacking;
+  const int plane = action / T, t = action % T;
+  const bool unit_lane = lane < r.n_units;
+  const int pl = unit_lane ? r.u_player[lane] : -1, tu = unit_lane ? r.u_turn[lane] : -1;
+  int st = unit_lane ? s.status[lane] : 99;
+  if (plane < r.placement_limit) {
+    const unsigned long long q = __ballot(pl == s.player && tu == s.turn && st == SCS_QUEUED);
+    const int u = __ffsll((long long)q) - 1;
+    if (lane == 0) {
+      s.status[u] = SCS_AVAILABLE;
+      s.tile[u] = (int8_t)t;
+      game.place(u, t);
+    }
+  } else if (lane == 0) {
+    if (plane < r.movement_limit) {
+      const int idx = plane - r.placement_limit, lvl = idx % S, dir = idx / S;
+      const int u = s.stack[t][lvl], dest = r.neighbour[t][dir];
+      s.mov[u] = (int8_t)(s.mov[u] - r.cost[dest]);
+      s.tile[u] = (int8_t)dest;
+      game.place(u, dest);
+      game.remove(u, t);
+      bool any = false;
+      for (int d = 0; d < 6; ++d) any |= game.can_move(u, d, false);
+      if (!any) game.end_movement(u);
+    } else if (plane < r.target_limit) {
+      s.target = (int8_t)t;
+    } else if (plane < r.attackers_limit) {
+      s.attackers[s.n_attackers++] = s.stack[t][plane - r.target_limit];
+    } else if (plane < r.confirm_limit) {
+      game.resolve_combat();
+      s.target = -1;
+      s.n_attackers = 0;
+    } else if (plane < r.no_move_limit) {
+      game.end_movement(s.stack[t][plane - r.confirm_limit]);
+    } else {
+      game.end_fighting(s.stack[t][plane - r.no_move_limit]);
+    }
+  }
+  if (lane == 0) ++s.length;
+  __syncthreads();
+  st = unit_lane ? s.status[lane] : 99;
+  int stage = s.stage, turn = s.turn;
+  const int target = s.target;
+  bool done = false;
+  auto none = [&](bool pred) { return __ballot(pred) == 0ull; };
+  for (;;) {
+    if (stage == -2) {
+      if (none(pl == 0 && tu == turn && st == SCS_QUEUED)) { ++stage; continue; }
+    } else if (stage == -1) {
+      if (none(pl == 1 && tu == turn && st == SCS_QUEUED)) { ++turn; ++stage; continue; }
+    } else if (stage == 0 || stage == 4) {
+      if (none(pl == (stage >> 2) && tu == turn && st == SCS_QUEUED)) { ++stage; continue; }
+    } else if (stage == 1 || stage == 5) {
+      if (none(pl == (stage >> 2) && st == SCS_AVAILABLE)) { ++stage; continue; }
+    } else if (stage == 2) {
+      if (none(pl == 0 && st == SCS_MOVED)) { stage = 4; continue; }
+      if (target >= 0) { ++stage; continue; }
+    } else if (stage == 6) {
+      if (none(pl == 1 && st == SCS_MOVED)) {
+        if (turn + 1 > r.turns) { done = true; break; }
+        ++turn;
+        stage = 0;
+        if (st == SCS_ATTACKED) {                       // new_turn (:845-855)
+          st = SCS_AVAILABLE;
+          s.status[lane] = SCS_AVAILABLE;
+          s.mov[lane] = r.u_mov[lane];
+        }
+        continue;
+      }
+      if (target >= 0) { ++stage; continue; }
+    } else {   // 3, 7
+      if (target < 0) { --stage; continue; }
+    }
+    break;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    s.turn = (int16_t)turn;
+    s.player = (stage == -2 || (stage >= 0 && stage <= 3)) ? 0 : 1;
+    if (done) {
+      s.terminal = 1;
+      game.check_termination();
+    }
+    s.sub_phase = (stage == -2 || stage == -1 || stage == 0 || stage == 4) ? 0
+                  : (stage == 1 || stage == 5) ? 1 : (stage == 2 || stage == 6) ? 2 : 3;
+    s.stage = (int16_t)stage;
+  }
+  __syncthreads();
+}
+
 }  // namespace nz

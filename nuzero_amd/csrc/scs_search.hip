@@ -17,6 +17,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -330,10 +332,8 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
         if (os > score || (os == score && ok > key)) { score = os; key = ok; }
       }
       node = parent.child_base + (key & 0xff);
-      if (lane == 0) {
-        Scs(R, sc).step(key >> 8);
-        path[plen] = node;
-      }
+      if (lane == 0) path[plen] = node;
+      scs_step_wave(R, sc, key >> 8, lane);
       ++plen;
     }
     if (bad) {
@@ -724,6 +724,7 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
     }
     hipLaunchKernelGGL(begin_move_kernel, dim3(G), dim3(64), 0, s, h->p, h->noise);
     h->p.terminal_budget = 16;
+    if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     const int sims = h->cfg.mcts_simulations;
     for (int w = 0;; ++w) {
       S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
