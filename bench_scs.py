@@ -20,6 +20,33 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 
+def cpu_baseline(config_path, weights, layers, search, seconds):
+    """The CPU oracle (oracle/scs.py rules + oracle/search.py Explorer + oracle/net.py ConvNet, the
+    restatement of the reference's path) on a bounded sample: moves of one self-play game until
+    `seconds` have passed, one process, one torch thread."""
+    import torch
+    from oracle import search as osearch
+    from oracle.net import FeedForwardRef
+    from oracle.scs import ScsConfig, ScsGame
+    torch.set_num_threads(1)
+    net = FeedForwardRef(weights, "convnet", layers)
+    ev = osearch.net_evaluator(net, None)
+    game = ScsGame(ScsConfig(config_path))
+    explorer = osearch.Explorer(search, True, np.random.RandomState(0))
+    root = osearch.Node(0)
+    t0 = time.perf_counter()
+    moves = 0
+    while not game.is_terminal() and time.perf_counter() - t0 < seconds:
+        action, chosen, _ = explorer.run_mcts(game, ev, root)
+        game.step_index(action)
+        root = chosen
+        moves += 1
+    dt = time.perf_counter() - t0
+    return {"expansions_per_s": explorer.counters.expansions / dt, "simulations_per_s": explorer.counters.simulations / dt,
+            "moves_per_s": moves / dt, "cores": 1, "kind": "port",
+            "sample": "%d moves of one game (%d simulations) in %.1f s" % (moves, explorer.counters.simulations, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--games", type=int, default=1024)
@@ -29,6 +56,9 @@ def main():
     ap.add_argument("--evaluator", choices=["native", "torch"], default="native")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
+    ap.add_argument("--nodes-per-sim", type=int, default=2048,
+                    help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game)")
+    ap.add_argument("--cpu-seconds", type=float, default=0.0, help="also time the CPU oracle for this long")
     ap.add_argument("--config", default=os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
     args = ap.parse_args()
     import torch
@@ -71,7 +101,7 @@ def main():
                               "epsilon_random_exploration": 0.001, "value_factor": 1,
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
-    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * 40 * 128)
+    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * args.nodes_per_sim)
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -81,6 +111,11 @@ def main():
         r = sp.play(ev, seeds=range(args.games))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    out = {}
+    if args.cpu_seconds > 0:
+        base = cpu_baseline(args.config, w, args.layers, search, args.cpu_seconds)
+        base["games_per_s_estimate"] = base["moves_per_s"] / float(r["lengths"].mean())
+        out["cpu_baseline"] = base
     print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, ConvNet(%d filters, %d layers, "
                                   "square convs), %s evaluator, %s move loop" % (
                                       cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, args.filters, args.layers,
@@ -89,7 +124,7 @@ def main():
                       "games_per_s": args.games / dt, "expansions_per_s": r["expansions"] / dt,
                       "simulations_per_s": r["simulations"] / dt, "seconds": dt,
                       "mean_game_length": float(r["lengths"].mean()),
-                      "outcomes": {str(v): int((r["outcomes"] == v).sum()) for v in (-1, 0, 1)}}))
+                      "outcomes": {str(v): int((r["outcomes"] == v).sum()) for v in (-1, 0, 1)}, **out}))
 
 
 if __name__ == "__main__":

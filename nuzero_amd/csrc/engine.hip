@@ -135,23 +135,49 @@ struct PackedConv {
   int cout, cin, cin_main, kgroups, ntiles, extra;
   int32_t w_off, wx_off;
 };
+// a = p[0] + p[1] + p[2] exactly, each piece a bf16 number (the next 8 significant bits, truncated)
+static void split3(float a, uint16_t p[3]) {
+  float r = a;
+  for (int i = 0; i < 3; ++i) {
+    uint32_t bits;
+    memcpy(&bits, &r, 4);
+    bits &= 0xFFFF0000u;
+    p[i] = (uint16_t)(bits >> 16);
+    float t;
+    memcpy(&t, &bits, 4);
+    r = r - t;
+  }
+}
 PackedConv pack_conv(const float* w, int cout, int cin, int cin_main, std::vector<float>& out) {
   PackedConv pc{};
   pc.cout = cout; pc.cin = cin; pc.cin_main = cin_main;
   pc.ntiles = (cout + 15) / 16;
-  pc.kgroups = (cin_main + 15) / 16;
+  pc.kgroups = (cin_main + NET_KG_CHANNELS - 1) / NET_KG_CHANNELS;
   pc.extra = cin > cin_main ? 1 : 0;
   while (out.size() % 4) out.push_back(0.f);
   pc.w_off = (int32_t)out.size();
+  auto weight = [&](int co, int ci, int t) { return co < cout && ci < cin_main ? w[((size_t)co * cin + ci) * 9 + t] : 0.f; };
   for (int nt = 0; nt < pc.ntiles; ++nt)
     for (int kg = 0; kg < pc.kgroups; ++kg)
-      for (int t = 0; t < 9; ++t)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 4; ++j) {
-            const int co = nt * 16 + (lane & 15);
-            const int ci = kg * 16 + (lane >> 4) * 4 + j;
-            out.push_back(co < cout && ci < cin_main ? w[((size_t)co * cin + ci) * 9 + t] : 0.f);
-          }
+      for (int t = 0; t < 9; ++t) {
+        if (!NET_SPLIT) {
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) out.push_back(weight(nt * 16 + (lane & 15), kg * 16 + (lane >> 4) * 4 + j, t));
+        } else {
+          for (int piece = 0; piece < 3; ++piece)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int pr = 0; pr < 4; ++pr) {       // lane holds channels 32 kg + 8 (lane >> 4) + 0..7 as 4 bf16 pairs
+                uint16_t lo[3], hi[3];
+                const int co = nt * 16 + (lane & 15), ci = kg * 32 + (lane >> 4) * 8 + 2 * pr;
+                split3(weight(co, ci, t), lo);
+                split3(weight(co, ci + 1, t), hi);
+                const uint32_t word = (uint32_t)lo[piece] | ((uint32_t)hi[piece] << 16);
+                float f;
+                memcpy(&f, &word, 4);
+                out.push_back(f);
+              }
+        }
+      }
   pc.wx_off = (int32_t)out.size();
   if (pc.extra)
     for (int nt = 0; nt < pc.ntiles; ++nt)
@@ -181,14 +207,14 @@ bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::
       const int og_first = sc.split ? 1 : 0, og_last = sc.split ? 4 : 0;
       for (int og = og_first; og <= og_last; ++og) {
         NetJob j{};
-        j.w_off = pc.w_off + nt * pc.kgroups * 9 * 256;
+        j.w_off = pc.w_off + nt * pc.kgroups * NET_KG_DWORDS;
         j.wx_off = pc.wx_off + nt * 9 * 64;
         j.kgroups = (int16_t)pc.kgroups;
         j.nt = (int16_t)nt;
         j.extra = (int8_t)pc.extra;
         j.og = (int8_t)og;
         j.src = (int8_t)sc.src; j.dst = (int8_t)sc.dst; j.res = (int8_t)sc.res; j.act = (int8_t)sc.act;
-        units.push_back({j, og_taps[og] * (4 * pc.kgroups + pc.extra)});
+        units.push_back({j, og_taps[og] * ((NET_SPLIT ? 3 : 4) * pc.kgroups + pc.extra)});   // ~MFMA time
       }
     }
   }

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(NET_THREADS) void net_kernel(const NetProgram* __re
   const int tile0 = blockIdx.x * POS;
   if (tile0 >= count) return;
 
+  // K groups may reach past a narrow layer's channels (their weights are zero): no NaN bit patterns in LDS
+  for (int idx = threadIdx.x; idx < NET_BUFFERS * ACT_FLOATS; idx += NET_THREADS) lds[idx] = 0.0f;
   // input planes -> inp[cell][pos][4]
   for (int idx = threadIdx.x; idx < CELLS * POS * 4; idx += NET_THREADS) {
     const int c = idx & 3, pp = (idx >> 2) & 15, cell = idx >> 6;

@@ -37,6 +37,8 @@
 // the position so that ds_read_b128 (A operands) and ds_write_b32 (epilogue) are
 // bank-conflict free.
 #pragma once
+#include <type_traits>
+
 #include "engine.h"
 
 namespace nz {
@@ -52,7 +54,7 @@ constexpr int NET_BUFFERS = 3;
 constexpr int ACT_FLOATS = CELLS * POS * ROW;
 constexpr int INP_FLOATS = CELLS * POS * 4;
 constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
-constexpr int W_KG_FLOATS = 9 * 64 * 4;   // one K group of one n-tile: [tap][lane][4]
+constexpr int W_KG_FLOATS = NET_KG_DWORDS; // one K group of one n-tile: [tap][lane][4] (FP32) / [tap][piece][lane][8 bf16]
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
 
 // output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} (taps: 49 | 13, 12, 12, 12)
@@ -165,6 +167,118 @@ __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], Frag& f0, Frag& f
     mfma_group<OMASK>(acc, f0);
 #pragma unroll
     for (int t = 0; t < 9; ++t) f0.b[t] = f1.b[t];
+  }
+}
+
+// ---- split form: float32 products from six bf16 MFMAs (engine.h NET_SPLIT) ----------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TAP_DWORDS = 3 * 64 * 4;      // one tap of one K group: [piece][lane][8 bf16]
+constexpr int W_RING = 3;                   // taps in flight; 9 taps per K group keep the slots aligned
+struct TapB {             // one tap's weights: the three pieces of this lane's 8 channels
+  u32x4 p[3];
+};
+struct FragS {            // the wavefront's weight stream, W_RING taps ahead of the MFMAs
+  TapB rb[W_RING];
+};
+struct SplitA {           // one input cell's activations, this lane's 8 channels, as three bf16 pieces
+  u32x4 p[3];
+};
+
+__device__ __forceinline__ uint32_t trunc_bf16(float x) { return __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u; }
+// (x0, x1) -> the two upper halves in one register: bf16(x0) | bf16(x1) << 16 (truncating)
+__device__ __forceinline__ uint32_t pack_hi16(float x0, float x1) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, x0), 0x07060302u);
+}
+// exact: x = p0 + p1 + p2 with 8 significant bits each; element j of the result = pair j's word
+template <int J>
+__device__ __forceinline__ void split_pair(float x0, float x1, SplitA& out) {
+  out.p[0][J] = pack_hi16(x0, x1);
+  const float r0 = x0 - __builtin_bit_cast(float, trunc_bf16(x0));
+  const float r1 = x1 - __builtin_bit_cast(float, trunc_bf16(x1));
+  out.p[1][J] = pack_hi16(r0, r1);
+  const float s0 = r0 - __builtin_bit_cast(float, trunc_bf16(r0));
+  const float s1 = r1 - __builtin_bit_cast(float, trunc_bf16(r1));
+  out.p[2][J] = pack_hi16(s0, s1);
+}
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, SplitA& out) {
+  split_pair<0>(lo[0], lo[1], out);
+  split_pair<1>(lo[2], lo[3], out);
+  split_pair<2>(hi[0], hi[1], out);
+  split_pair<3>(hi[2], hi[3], out);
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int OMASK, int I, int TAP>
+__device__ __forceinline__ void split_pair_mfma(f32x4 (&acc)[CELLS], const SplitA (&a)[CELLS], const TapB& b) {
+  if constexpr (pair_used<OMASK, I, TAP>()) {
+    constexpr int o = TapMap<I, TAP>::o;
+    // small terms first; one accumulator chain issues at the full rate
+    acc[o] = mfma_bf16(a[I].p[1], b.p[1], acc[o]);
+    acc[o] = mfma_bf16(a[I].p[2], b.p[0], acc[o]);
+    acc[o] = mfma_bf16(a[I].p[0], b.p[2], acc[o]);
+    acc[o] = mfma_bf16(a[I].p[1], b.p[0], acc[o]);
+    acc[o] = mfma_bf16(a[I].p[0], b.p[1], acc[o]);
+    acc[o] = mfma_bf16(a[I].p[0], b.p[0], acc[o]);
+  }
+}
+// all (input cell, TAP) pairs of the job's output cells: independent accumulators
+template <int OMASK, int TAP>
+__device__ __forceinline__ void split_tap(f32x4 (&acc)[CELLS], const SplitA (&a)[CELLS], const TapB& b) {
+  split_pair_mfma<OMASK, 0, TAP>(acc, a, b); split_pair_mfma<OMASK, 1, TAP>(acc, a, b); split_pair_mfma<OMASK, 2, TAP>(acc, a, b);
+  split_pair_mfma<OMASK, 3, TAP>(acc, a, b); split_pair_mfma<OMASK, 4, TAP>(acc, a, b); split_pair_mfma<OMASK, 5, TAP>(acc, a, b);
+  split_pair_mfma<OMASK, 6, TAP>(acc, a, b); split_pair_mfma<OMASK, 7, TAP>(acc, a, b); split_pair_mfma<OMASK, 8, TAP>(acc, a, b);
+}
+template <int OMASK, int I>
+__device__ __forceinline__ void split_cell(SplitA (&a)[CELLS], const float* __restrict__ src, int a0, int a1) {
+  if constexpr (input_used<OMASK, I>()) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src + a0 + I * (POS * ROW));
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(src + a1 + I * (POS * ROW));
+    split8(lo, hi, a[I]);
+  }
+}
+__device__ __forceinline__ void load_tap(TapB& t, const float* __restrict__ w, int lane) {
+  const u32x4* __restrict__ p = reinterpret_cast<const u32x4*>(w) + lane;
+  t.p[0] = p[0];
+  t.p[1] = p[64];
+  t.p[2] = p[128];
+}
+__device__ __forceinline__ void load_b(FragS& f, const float* __restrict__ w, int lane) {   // the first W_RING taps
+#pragma unroll
+  for (int i = 0; i < W_RING; ++i) load_tap(f.rb[i], w + i * TAP_DWORDS, lane);
+}
+// All K groups (32 channels each) of one job, tap-major.  On entry the ring holds the job's first
+// W_RING taps; on exit those of the next job that reads weights (`w_after`, may be null): the
+// weight stream stays W_RING taps ahead, also across jobs and stage barriers.  Per K group the
+// lane reads its 8 channels of every used input cell from LDS (2 x ds_read_b128) and splits them.
+template <int OMASK>
+__device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, FragS&, const float* __restrict__ src,
+                                          const float* __restrict__ w, int kgroups,
+                                          const float* __restrict__ w_after, int lane) {
+  const int pos = lane & 15, quad = lane >> 4;
+  const int n_taps = kgroups * 9;
+  auto refill = [&](TapB& slot, int t) {          // t = stream index of the tap to fetch
+    if (t < n_taps) load_tap(slot, w + t * TAP_DWORDS, lane);
+    else if (w_after != nullptr) load_tap(slot, w_after + (t - n_taps) * TAP_DWORDS, lane);
+  };
+  for (int kg = 0; kg < kgroups; ++kg) {
+    const int a0 = act_addr(0, pos, kg * 32 + quad * 8), a1 = act_addr(0, pos, kg * 32 + quad * 8 + 4);
+    SplitA a[CELLS];
+    split_cell<OMASK, 0>(a, src, a0, a1); split_cell<OMASK, 1>(a, src, a0, a1); split_cell<OMASK, 2>(a, src, a0, a1);
+    split_cell<OMASK, 3>(a, src, a0, a1); split_cell<OMASK, 4>(a, src, a0, a1); split_cell<OMASK, 5>(a, src, a0, a1);
+    split_cell<OMASK, 6>(a, src, a0, a1); split_cell<OMASK, 7>(a, src, a0, a1); split_cell<OMASK, 8>(a, src, a0, a1);
+    const int t0 = kg * 9 + W_RING;
+    split_tap<OMASK, 0>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 0);
+    split_tap<OMASK, 1>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 1);
+    split_tap<OMASK, 2>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 2);
+    split_tap<OMASK, 3>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 3);
+    split_tap<OMASK, 4>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 4);
+    split_tap<OMASK, 5>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 5);
+    split_tap<OMASK, 6>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 6);
+    split_tap<OMASK, 7>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 7);
+    split_tap<OMASK, 8>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 8);
   }
 }
 
@@ -281,8 +395,20 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
 }
 
 // one job: K loop, input-plane step, epilogue
+using NetOperands = typename std::conditional<NET_SPLIT, FragS, Frag>::type;
+__device__ __forceinline__ void zero_b(Frag& f) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) f.b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void zero_b(FragS& f) {
+#pragma unroll
+  for (int t = 0; t < W_RING; ++t)
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
+}
+
 template <int OMASK, typename Stamp>
-__device__ __forceinline__ void run_job(const NetJob& job, Frag& f0, Frag& f1, const float* __restrict__ W,
+__device__ __forceinline__ void run_job(const NetJob& job, NetOperands& f0, NetOperands& f1, const float* __restrict__ W,
                                         const float* w_after, float* __restrict__ lds,
                                         const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
                                         float* logits, float* value, Stamp&& stamp) {
@@ -315,9 +441,8 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   const NetJob* __restrict__ jobs = prog->jobs[wave];
   const int n_jobs = prog->n_jobs[wave];
 
-  Frag f0, f1;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) f0.b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  NetOperands f0, f1;
+  zero_b(f0);
   if (prog->first_w_off[wave] >= 0) load_b(f0, W + prog->first_w_off[wave], lane);
 
   unsigned long long tk[4] = {0, 0, 0, 0}, ts = 0;

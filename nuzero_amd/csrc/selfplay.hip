@@ -50,6 +50,8 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
   float* const out_value = out_logits + POS * TTT_ACTIONS;
 
   const int tid = threadIdx.x;
+  // K groups may reach past a narrow layer's channels (their weights are zero): no NaN bit patterns in LDS
+  for (int idx = tid; idx < NET_BUFFERS * ACT_FLOATS; idx += NET_THREADS) lds[idx] = 0.0f;
   const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
   const int sub = tid & (LANES_PER_GAME - 1);
   const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
