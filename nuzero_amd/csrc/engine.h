@@ -100,36 +100,28 @@ void launch_selfplay(const TreeParams& p, const struct NetProgram* prog_dev, int
                      const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s);
 
 // ---- network ----------------------------------------------------------------
-// Arithmetic of the fused network (net_dev.hpp).  Every float32 product a * w is formed on the
-// BF16 matrix cores from exact three-way splits a = a0 + a1 + a2, w = w0 + w1 + w2 (each piece
-// the next 8 significant bits, i.e. a bf16 number) as the six terms a0w0 + a0w1 + a1w0 + a0w2 +
-// a2w0 + a1w1, accumulated in float32: the dropped terms are below 2^-23 |a w|, the float32
-// rounding of the product itself.  v_mfma_f32_16x16x32_bf16 runs at 16x the FP32 MFMA rate, so
-// six of them per 32 channels take 96 cycles against 256 for eight v_mfma_f32_16x16x4_f32.
-// -DNZ_NET_F32 builds the plain FP32-MFMA form (16-channel K groups) for comparison.
-#ifdef NZ_NET_F32
-constexpr bool NET_SPLIT = false;
-#else
-constexpr bool NET_SPLIT = true;
-#endif
-constexpr int NET_KG_CHANNELS = NET_SPLIT ? 32 : 16;                     // channels per K group
-constexpr int NET_KG_DWORDS = NET_SPLIT ? 9 * 3 * 64 * 4 : 9 * 64 * 4;   // packed weights of one K group of one n-tile
+// Arithmetic of the fused network: net_dev.hpp.  K groups are 32 channels; the packed weights of
+// one K group of one 16-channel output tile are [tap][piece][lane][8 bf16].
+constexpr int NET_KG_CHANNELS = 32;
+constexpr int NET_KG_DWORDS = 9 * 3 * 64 * 4;
+constexpr int NET_ACT_BUFFERS = 2;                 // activation buffers in LDS (ping-pong)
+constexpr int NET_DST_POLICY = NET_ACT_BUFFERS;    // NetJob::dst: policy logits out
+constexpr int NET_DST_VALUE = NET_ACT_BUFFERS + 1; // NetJob::dst: value out
 
 // The network is compiled on the host into one job list per wave (net_dev.hpp).
 // A job is one (conv layer, 16-channel output tile, output-cell group) unit; the
 // jobs of a stage are independent, a workgroup barrier separates stages.
 struct NetJob {
-  int32_t w_off;       // dword offset of this (layer, n-tile)'s packed main weights: [kgroup][tap][lane][4 f32],
-                       // or with NET_SPLIT [kgroup of 32 ch][tap][piece][lane][8 bf16]
+  int32_t w_off;       // dword offset of this (layer, n-tile)'s packed main weights [kgroup][tap][piece][lane][8 bf16]
   int32_t wx_off;      // float offset of its packed input-plane weights [tap][lane]
   int32_t next_w_off;  // w_off of the next job of this wave that reads weights, or -1 (prefetch target)
-  int16_t kgroups;     // K groups (NET_KG_CHANNELS channels each) read from the source activation buffer
+  int16_t kgroups;     // 32-channel K groups read from the source activation buffer
   int16_t nt;          // output tile: channels 16 nt .. 16 nt + 15
   int8_t extra;        // 1: also read the (<= 4) input planes as one extra K step
   int8_t og;           // output-cell group (net_dev.hpp OG_MASK); OG_NONE = no work, barrier only
-  int8_t src, dst;     // activation buffers 0..2; dst 3 = policy logits out, 4 = value out
+  int8_t src, dst;     // activation buffers 0..1; dst NET_DST_POLICY / NET_DST_VALUE = network outputs
   int8_t res;          // residual buffer or -1
-  int8_t act;          // 0 none, 1 relu, 2 tanh
+  int8_t act;          // 0 none, 1 relu, 2 tanh, 3 elu
   int8_t stage_end;    // 1: workgroup barrier after this job
   int8_t pad;
 };

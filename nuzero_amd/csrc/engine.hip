@@ -129,8 +129,9 @@ int head_channel(int width, int out, int n_layers, int idx) {   // blocks.py:56-
 }
 
 // One conv tensor repacked for the MFMA kernel (net_dev.hpp): per 16-channel output
-// tile nt a contiguous weight stream main[nt][kgroup][tap][lane][4] and, for the two
-// convs that also read the raw input planes, extra[nt][tap][lane].
+// tile nt a contiguous weight stream main[nt][kgroup of 32 ch][tap][piece][lane][8 bf16] (the
+// three exact bf16 pieces of every weight) and, for the two convs that also read the raw
+// input planes, extra[nt][tap][lane] in float32.
 struct PackedConv {
   int cout, cin, cin_main, kgroups, ntiles, extra;
   int32_t w_off, wx_off;
@@ -159,25 +160,19 @@ PackedConv pack_conv(const float* w, int cout, int cin, int cin_main, std::vecto
   auto weight = [&](int co, int ci, int t) { return co < cout && ci < cin_main ? w[((size_t)co * cin + ci) * 9 + t] : 0.f; };
   for (int nt = 0; nt < pc.ntiles; ++nt)
     for (int kg = 0; kg < pc.kgroups; ++kg)
-      for (int t = 0; t < 9; ++t) {
-        if (!NET_SPLIT) {
+      for (int t = 0; t < 9; ++t)
+        for (int piece = 0; piece < 3; ++piece)
           for (int lane = 0; lane < 64; ++lane)
-            for (int j = 0; j < 4; ++j) out.push_back(weight(nt * 16 + (lane & 15), kg * 16 + (lane >> 4) * 4 + j, t));
-        } else {
-          for (int piece = 0; piece < 3; ++piece)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int pr = 0; pr < 4; ++pr) {       // lane holds channels 32 kg + 8 (lane >> 4) + 0..7 as 4 bf16 pairs
-                uint16_t lo[3], hi[3];
-                const int co = nt * 16 + (lane & 15), ci = kg * 32 + (lane >> 4) * 8 + 2 * pr;
-                split3(weight(co, ci, t), lo);
-                split3(weight(co, ci + 1, t), hi);
-                const uint32_t word = (uint32_t)lo[piece] | ((uint32_t)hi[piece] << 16);
-                float f;
-                memcpy(&f, &word, 4);
-                out.push_back(f);
-              }
-        }
-      }
+            for (int pr = 0; pr < 4; ++pr) {       // lane holds channels 32 kg + 8 (lane >> 4) + 0..7 as 4 bf16 pairs
+              uint16_t lo[3], hi[3];
+              const int co = nt * 16 + (lane & 15), ci = kg * 32 + (lane >> 4) * 8 + 2 * pr;
+              split3(weight(co, ci, t), lo);
+              split3(weight(co, ci + 1, t), hi);
+              const uint32_t word = (uint32_t)lo[piece] | ((uint32_t)hi[piece] << 16);
+              float f;
+              memcpy(&f, &word, 4);
+              out.push_back(f);
+            }
   pc.wx_off = (int32_t)out.size();
   if (pc.extra)
     for (int nt = 0; nt < pc.ntiles; ++nt)
@@ -214,7 +209,7 @@ bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::
         j.extra = (int8_t)pc.extra;
         j.og = (int8_t)og;
         j.src = (int8_t)sc.src; j.dst = (int8_t)sc.dst; j.res = (int8_t)sc.res; j.act = (int8_t)sc.act;
-        units.push_back({j, og_taps[og] * ((NET_SPLIT ? 3 : 4) * pc.kgroups + pc.extra)});   // ~MFMA time
+        units.push_back({j, og_taps[og] * (3 * pc.kgroups + pc.extra)});   // ~MFMA time in units of 32 cycles
       }
     }
   }
@@ -465,8 +460,8 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
     convs[i] = pack_conv(host[i].data(), shapes[i].cout, shapes[i].cin, cin_main, packed);
   }
 
-  // stages; activation buffers 0/1 ping-pong, `cur` holds the running trunk output, 2 is the
-  // value head's side buffer; dst 3 = policy logits, 4 = value.  act: 1 relu, 2 tanh, 3 elu
+  // stages; activation buffers 0/1 ping-pong, `cur` holds the running trunk output.
+  // act: 1 relu, 2 tanh, 3 elu
   NetProgram& pg = e->prog_host;
   memset(&pg, 0, sizeof(pg));
   bool ok = true;
@@ -493,10 +488,14 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   const int ph = trunk_tensors, vh = ph + 2;
   const int vact = net->value_activation == NZ_ACT_RELU ? 1 : 2;
   const int side = cur ^ 1;
-  stage({{ph, cur, side, -1, 1, true}, {vh, cur, 2, -1, vact, true}});      // both heads read the trunk output
-  stage({{ph + 1, side, 3, -1, 0, true}, {vh + 1, 2, cur, -1, vact, true}});
+  // two buffers: the policy head runs first (trunk -> side -> logits), then the value head
+  // ping-pongs between the two (the trunk output is dead after its first layer)
+  stage({{ph, cur, side, -1, 1, true}});
+  stage({{ph + 1, side, NET_DST_POLICY, -1, 0, true}});
+  stage({{vh, cur, side, -1, vact, true}});
+  stage({{vh + 1, side, cur, -1, vact, true}});
   stage({{vh + 2, cur, side, -1, vact, true}});
-  stage({{vh + 3, side, 4, -1, 0, false}});                                 // mean over cells needs all nine
+  stage({{vh + 3, side, NET_DST_VALUE, -1, 0, false}});                     // mean over cells needs all nine
   if (!ok) return fail(e, NZ_ERR_ARG, "network too deep for one fused launch (%d iterations)", recurrent_iterations);
   for (int w = 0; w < NET_WAVES_HOST; ++w) {     // prefetch chain: each job names the next weight stream
     int32_t next = -1;

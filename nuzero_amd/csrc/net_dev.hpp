@@ -1,9 +1,9 @@
-// Fused policy/value network for one tile of 16 positions (gfx950, FP32 MFMA).
+// Fused policy/value network for one tile of 16 positions (gfx950 matrix cores).
 // Device function shared by the stand-alone network kernel (net.hip) and the
 // persistent self-play kernel (selfplay.hip).
 //
 // Computes Network_Manager.inference (Neural_Networks/Network_Manager.py:46-64)
-// for the square-conv RecurrentNet (Neural_Networks/Architectures/
+// for the square-conv RecurrentNet / ResNet / ConvNet (Neural_Networks/Architectures/
 // RecurrentNet.py:82-99; BasicBlock blocks.py:37-41; Reduce_PolicyHead
 // blocks.py:130-170; Reduce_ValueHead blocks.py:46-92) on a batch of 3x3 boards:
 // every conv is 3x3, stride 1, zero 'same' padding, bias-free.
@@ -13,57 +13,75 @@
 //
 // Mapping.  On a 3x3 board with a 3x3 kernel every output cell o sees input
 // cell i through exactly one tap (tap = i - o + centre) when |dy|,|dx| <= 1, so
-// a conv layer is, per output cell, a dense [16 positions] x [C_in * n_valid(o)]
-// x [C_out] product.  The zero-padding taps are never multiplied: 49 of the 81
-// (cell, tap) pairs exist.  v_mfma_f32_16x16x4_f32 takes M = 16 positions,
-// N = 16 output channels, K = 4 input channels; lane l supplies A[pos = l & 15]
-// [k = l >> 4] and B[k = l >> 4][cout = l & 15] and receives C[pos = 4*(l>>4)+r]
-// [cout = l & 15] in register r.  FP32 inputs/accumulation are required by the
-// 1e-5 parity tolerance; the MFMA result is an exact k-ordered fmaf chain, and
-// each position's row is independent of the others, so a position's outputs do
-// not depend on which batch slot it occupies.
+// a conv layer is, per output cell, a dense [C_out] x [C_in * n_valid(o)] x
+// [16 positions] product.  The zero-padding taps are never multiplied: 49 of the 81
+// (cell, tap) pairs exist.
+//
+// Arithmetic.  Every float32 product a * w is formed on the BF16 matrix cores from exact
+// three-way splits a = a0 + a1 + a2, w = w0 + w1 + w2 (each piece the next 8 significant
+// bits, a bf16 number) as the six terms a1w1 + a2w0 + a0w2 + a1w0 + a0w1 + a0w0 accumulated
+// in float32; the dropped terms are below 2^-23 |a w|, the rounding of the float32 product
+// itself.  v_mfma_f32_16x16x32_bf16 runs at 16x the FP32 MFMA rate, so the six of them per
+// 32 channels take 96 cycles where eight v_mfma_f32_16x16x4_f32 take 256.  Measured against
+// float64-accumulated convolutions the result is closer than a plain float32 convolution
+// (DESIGN.md section 4).  The weights are split once on the host (engine.hip pack_conv), the
+// activations once per element in the epilogue that produces them: LDS holds the three bf16
+// pieces, the K loop reads them and issues MFMAs, nothing else.  The (<= 4) raw input planes of
+// the projection / recall convs go through one v_mfma_f32_16x16x4_f32 per pair.
+//
+// Orientation.  The weights are the MFMA's A operand (rows = 16 output channels), the
+// activations its B operand (columns = 16 positions): lane l supplies W[cout = l & 15]
+// [k = 8 (l >> 4) + j] and X[k = 8 (l >> 4) + j][pos = l & 15], j = 0..7, and receives
+// C[cout = 4 (l >> 4) + r][pos = l & 15] in register r -- four consecutive channels of one
+// position, which the epilogue splits and writes as one 8-byte LDS store per piece.  Each
+// position's column is independent of the others, so a position's outputs do not depend on
+// which batch slot it occupies.
 //
 // Work split.  The host compiles the network into one job list per wave
-// (engine.hip build_program): a job is one (layer, 16-channel output tile,
-// output-cell group).  64-channel layers give each of the 4 waves one full
-// tile; the narrow head layers are cut by output-cell group as well so that all
-// four matrix pipes stay busy, and the policy and value heads run side by side.
-// Per 16-channel K group a wave reads at most 9 activation vectors (one
-// ds_read_b128 per input cell) and 9 weight vectors (one global_load_dwordx4 per
-// tap) and issues up to 196 MFMAs from them; the weights of the NEXT K group --
-// also across jobs and barriers -- are already in flight while it does so.
+// (engine.hip): a job is one (layer, 16-channel output tile, output-cell group).
+// 64-channel layers give each of the 4 waves one full tile; the narrow head layers are cut
+// by output-cell group as well so that all four matrix pipes stay busy.  Per 32-channel K
+// group a wave reads 3 x 16 bytes per used input cell from LDS (the next K group's while
+// the MFMAs of this one run) and streams the weights tap by tap from L2, three taps ahead
+// of the MFMAs -- also across jobs and stage barriers.
 //
-// LDS layout: act[buf][cell][pos][64 ch], the 16-byte slot index XOR-ed with
-// the position so that ds_read_b128 (A operands) and ds_write_b32 (epilogue) are
-// bank-conflict free.
+// LDS layout: act[buffer][piece][cell][pos][64 ch] bf16, the 16-byte slot index XOR-ed with
+// (pos >> 1) & 7 so that ds_read_b128 (operands) and ds_write_b64 (epilogue) are
+// bank-conflict free.  Two buffers (ping-pong; residual blocks update in place).
 #pragma once
-#include <type_traits>
-
 #include "engine.h"
 
 namespace nz {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int POS = 16;            // positions per workgroup (MFMA M)
+constexpr int POS = 16;            // positions per workgroup (MFMA N)
 constexpr int CELLS = 9;
 constexpr int ROW = 64;            // channels per (cell, pos) row
 constexpr int NET_WAVES = 4;
 constexpr int NET_THREADS = NET_WAVES * 64;
-constexpr int NET_BUFFERS = 3;
-constexpr int ACT_FLOATS = CELLS * POS * ROW;
+constexpr int NET_BUFFERS = NET_ACT_BUFFERS;
+constexpr int PIECE_BYTES = CELLS * POS * ROW * 2;          // one bf16 piece of one buffer
+constexpr int ACT_BYTES = 3 * PIECE_BYTES;
+constexpr int ACT_FLOATS = ACT_BYTES / 4;                   // LDS is declared as float[] by the kernels
 constexpr int INP_FLOATS = CELLS * POS * 4;
 constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
-constexpr int W_KG_FLOATS = NET_KG_DWORDS; // one K group of one n-tile: [tap][lane][4] (FP32) / [tap][piece][lane][8 bf16]
+constexpr int TAP_DWORDS = 3 * 64 * 4;                      // one tap of one K group: [piece][lane][8 bf16]
+constexpr int W_RING = 3;                                   // taps in flight; 9 taps per K group keep the slots aligned
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
+static_assert(NET_KG_DWORDS == 9 * TAP_DWORDS && NET_KG_CHANNELS == 32, "host packing (engine.hip) and kernel agree");
 
 // output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} (taps: 49 | 13, 12, 12, 12)
 __host__ __device__ constexpr int og_mask(int og) {
   return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 : 0;
 }
 
-__device__ __forceinline__ int act_addr(int cell, int pos, int ch) {
-  return ((cell * POS + pos) << 6) + ((((ch >> 2) ^ pos) & 15) << 2) + (ch & 3);
+// byte offset of the 16-byte slot holding channels 8 s .. 8 s + 7 of (cell, pos) inside one piece
+__device__ __forceinline__ int slot_addr(int cell, int pos, int s) {
+  return ((cell * POS + pos) << 7) + (((s ^ (pos >> 1)) & 7) << 4);
 }
 
 template <int I, int TAP>
@@ -82,203 +100,136 @@ constexpr bool input_used() {
          pair_used<OMASK, I, 6>() || pair_used<OMASK, I, 7>() || pair_used<OMASK, I, 8>();
 }
 
-struct Frag {          // operands of one 16-channel K group
-  f32x4 a[CELLS];      // activations per input cell: 4 consecutive channels of this lane's K slice
-  f32x4 b[9];          // weights per tap
-};
-
-template <int OMASK, int I, int TAP>
-__device__ __forceinline__ void mfma_pair(f32x4 (&acc)[CELLS], const Frag& f) {
-  if constexpr (pair_used<OMASK, I, TAP>()) {
-    constexpr int o = TapMap<I, TAP>::o;
-    // the four K sub-steps of one (input cell, tap) pair back to back: a single accumulator
-    // chain issues at the full rate (scripts/microbench/mfma_rate.hip)
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][0], f.b[TAP][0], acc[o], 0, 0, 0);
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][1], f.b[TAP][1], acc[o], 0, 0, 0);
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][2], f.b[TAP][2], acc[o], 0, 0, 0);
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[I][3], f.b[TAP][3], acc[o], 0, 0, 0);
-  }
-}
-// input-cell major: the MFMAs of cell I only need the I-th LDS read to have landed
-template <int OMASK, int I>
-__device__ __forceinline__ void mfma_cell(f32x4 (&acc)[CELLS], const Frag& f) {
-  mfma_pair<OMASK, I, 0>(acc, f); mfma_pair<OMASK, I, 1>(acc, f); mfma_pair<OMASK, I, 2>(acc, f);
-  mfma_pair<OMASK, I, 3>(acc, f); mfma_pair<OMASK, I, 4>(acc, f); mfma_pair<OMASK, I, 5>(acc, f);
-  mfma_pair<OMASK, I, 6>(acc, f); mfma_pair<OMASK, I, 7>(acc, f); mfma_pair<OMASK, I, 8>(acc, f);
-}
-template <int OMASK>
-__device__ __forceinline__ void mfma_group(f32x4 (&acc)[CELLS], const Frag& f) {
-  mfma_cell<OMASK, 0>(acc, f); mfma_cell<OMASK, 1>(acc, f); mfma_cell<OMASK, 2>(acc, f);
-  mfma_cell<OMASK, 3>(acc, f); mfma_cell<OMASK, 4>(acc, f); mfma_cell<OMASK, 5>(acc, f);
-  mfma_cell<OMASK, 6>(acc, f); mfma_cell<OMASK, 7>(acc, f); mfma_cell<OMASK, 8>(acc, f);
-}
-
-template <int OMASK, int I>
-__device__ __forceinline__ void load_a1(Frag& f, const float* __restrict__ src, int a0) {
-#ifdef NZ_ABLATE_A   // timing-only build: no LDS reads of the A operands (outputs are wrong)
-  if constexpr (input_used<OMASK, I>()) { const float v = (float)(a0 + I); f.a[I] = f32x4{v, v + 1.f, v + 2.f, v + 3.f}; asm volatile("" :: "v"(src)); }
-#else
-  if constexpr (input_used<OMASK, I>()) f.a[I] = *reinterpret_cast<const f32x4*>(src + a0 + I * (POS * ROW));
-#endif
-}
-// this lane's activation operands of K group kg (address of cell 0; cell I is I*1024 floats further)
-template <int OMASK>
-__device__ __forceinline__ void load_a(Frag& f, const float* __restrict__ src, int pos, int quad, int kg) {
-  const int a0 = act_addr(0, pos, kg * 16 + quad * 4);
-  load_a1<OMASK, 0>(f, src, a0); load_a1<OMASK, 1>(f, src, a0); load_a1<OMASK, 2>(f, src, a0);
-  load_a1<OMASK, 3>(f, src, a0); load_a1<OMASK, 4>(f, src, a0); load_a1<OMASK, 5>(f, src, a0);
-  load_a1<OMASK, 6>(f, src, a0); load_a1<OMASK, 7>(f, src, a0); load_a1<OMASK, 8>(f, src, a0);
-}
-__device__ __forceinline__ void load_b(Frag& f, const float* __restrict__ w, int lane) {
-#ifdef NZ_ABLATE_B   // timing-only build: no global loads of the B operands (outputs are wrong)
-  const float v = (float)lane * 1e-3f;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) f.b[t] = f32x4{v, v + (float)t, v, v};
-  asm volatile("" :: "v"(w));
-#else
-  const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(w) + lane;
-#pragma unroll
-  for (int t = 0; t < 9; ++t) f.b[t] = p[t * 64];
-#endif
-}
-
-// All K groups of one job.  On entry f0.b holds the weights of the job's first K group; on
-// exit it holds those of the next job's first K group (`w_after`, may be null): the weight
-// stream is always one K group ahead, also across jobs and stage barriers.  Unrolled by two
-// so that the two operand sets swap roles without register copies.
-template <int OMASK>
-__device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], Frag& f0, Frag& f1, const float* __restrict__ src,
-                                          const float* __restrict__ w, int kgroups,
-                                          const float* __restrict__ w_after, int lane) {
-  const int pos = lane & 15, quad = lane >> 4;
-  int kg = 0;
-  for (; kg + 2 <= kgroups; kg += 2) {
-    load_b(f1, w + (kg + 1) * W_KG_FLOATS, lane);
-    load_a<OMASK>(f0, src, pos, quad, kg);
-    load_a<OMASK>(f1, src, pos, quad, kg + 1);
-    mfma_group<OMASK>(acc, f0);
-    const float* w_nxt = (kg + 2 < kgroups) ? w + (kg + 2) * W_KG_FLOATS : w_after;
-    if (w_nxt != nullptr) load_b(f0, w_nxt, lane);
-    mfma_group<OMASK>(acc, f1);
-  }
-  if (kg < kgroups) {                 // odd tail
-    if (w_after != nullptr) load_b(f1, w_after, lane);
-    load_a<OMASK>(f0, src, pos, quad, kg);
-    mfma_group<OMASK>(acc, f0);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) f0.b[t] = f1.b[t];
-  }
-}
-
-// ---- split form: float32 products from six bf16 MFMAs (engine.h NET_SPLIT) ----------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int TAP_DWORDS = 3 * 64 * 4;      // one tap of one K group: [piece][lane][8 bf16]
-constexpr int W_RING = 3;                   // taps in flight; 9 taps per K group keep the slots aligned
-struct TapB {             // one tap's weights: the three pieces of this lane's 8 channels
+struct Pieces {           // the three bf16 pieces of 8 channels (one lane's share of a 32-channel K group)
   u32x4 p[3];
 };
 struct FragS {            // the wavefront's weight stream, W_RING taps ahead of the MFMAs
-  TapB rb[W_RING];
-};
-struct SplitA {           // one input cell's activations, this lane's 8 channels, as three bf16 pieces
-  u32x4 p[3];
+  Pieces rb[W_RING];
 };
 
+// ---- exact three-way split of float32 into bf16 pieces -------------------------------------------
 __device__ __forceinline__ uint32_t trunc_bf16(float x) { return __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u; }
 // (x0, x1) -> the two upper halves in one register: bf16(x0) | bf16(x1) << 16 (truncating)
 __device__ __forceinline__ uint32_t pack_hi16(float x0, float x1) {
   return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, x0), 0x07060302u);
 }
-// exact: x = p0 + p1 + p2 with 8 significant bits each; element j of the result = pair j's word
-template <int J>
-__device__ __forceinline__ void split_pair(float x0, float x1, SplitA& out) {
-  out.p[0][J] = pack_hi16(x0, x1);
+// x = p0 + p1 + p2 exactly, 8 significant bits each
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+  p0 = pack_hi16(x0, x1);
   const float r0 = x0 - __builtin_bit_cast(float, trunc_bf16(x0));
   const float r1 = x1 - __builtin_bit_cast(float, trunc_bf16(x1));
-  out.p[1][J] = pack_hi16(r0, r1);
+  p1 = pack_hi16(r0, r1);
   const float s0 = r0 - __builtin_bit_cast(float, trunc_bf16(r0));
   const float s1 = r1 - __builtin_bit_cast(float, trunc_bf16(r1));
-  out.p[2][J] = pack_hi16(s0, s1);
+  p2 = pack_hi16(s0, s1);
 }
-__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, SplitA& out) {
-  split_pair<0>(lo[0], lo[1], out);
-  split_pair<1>(lo[2], lo[3], out);
-  split_pair<2>(hi[0], hi[1], out);
-  split_pair<3>(hi[2], hi[3], out);
-}
-__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4& w, const u32x4& x, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 template <int OMASK, int I, int TAP>
-__device__ __forceinline__ void split_pair_mfma(f32x4 (&acc)[CELLS], const SplitA (&a)[CELLS], const TapB& b) {
+__device__ __forceinline__ void pair_mfma(f32x4 (&acc)[CELLS], const Pieces (&x)[CELLS], const Pieces& w) {
   if constexpr (pair_used<OMASK, I, TAP>()) {
     constexpr int o = TapMap<I, TAP>::o;
     // small terms first; one accumulator chain issues at the full rate
-    acc[o] = mfma_bf16(a[I].p[1], b.p[1], acc[o]);
-    acc[o] = mfma_bf16(a[I].p[2], b.p[0], acc[o]);
-    acc[o] = mfma_bf16(a[I].p[0], b.p[2], acc[o]);
-    acc[o] = mfma_bf16(a[I].p[1], b.p[0], acc[o]);
-    acc[o] = mfma_bf16(a[I].p[0], b.p[1], acc[o]);
-    acc[o] = mfma_bf16(a[I].p[0], b.p[0], acc[o]);
+    acc[o] = mfma_bf16(w.p[1], x[I].p[1], acc[o]);
+    acc[o] = mfma_bf16(w.p[0], x[I].p[2], acc[o]);
+    acc[o] = mfma_bf16(w.p[2], x[I].p[0], acc[o]);
+    acc[o] = mfma_bf16(w.p[0], x[I].p[1], acc[o]);
+    acc[o] = mfma_bf16(w.p[1], x[I].p[0], acc[o]);
+    acc[o] = mfma_bf16(w.p[0], x[I].p[0], acc[o]);
   }
 }
 // all (input cell, TAP) pairs of the job's output cells: independent accumulators
 template <int OMASK, int TAP>
-__device__ __forceinline__ void split_tap(f32x4 (&acc)[CELLS], const SplitA (&a)[CELLS], const TapB& b) {
-  split_pair_mfma<OMASK, 0, TAP>(acc, a, b); split_pair_mfma<OMASK, 1, TAP>(acc, a, b); split_pair_mfma<OMASK, 2, TAP>(acc, a, b);
-  split_pair_mfma<OMASK, 3, TAP>(acc, a, b); split_pair_mfma<OMASK, 4, TAP>(acc, a, b); split_pair_mfma<OMASK, 5, TAP>(acc, a, b);
-  split_pair_mfma<OMASK, 6, TAP>(acc, a, b); split_pair_mfma<OMASK, 7, TAP>(acc, a, b); split_pair_mfma<OMASK, 8, TAP>(acc, a, b);
+__device__ __forceinline__ void tap_mfma(f32x4 (&acc)[CELLS], const Pieces (&x)[CELLS], const Pieces& w) {
+  pair_mfma<OMASK, 0, TAP>(acc, x, w); pair_mfma<OMASK, 1, TAP>(acc, x, w); pair_mfma<OMASK, 2, TAP>(acc, x, w);
+  pair_mfma<OMASK, 3, TAP>(acc, x, w); pair_mfma<OMASK, 4, TAP>(acc, x, w); pair_mfma<OMASK, 5, TAP>(acc, x, w);
+  pair_mfma<OMASK, 6, TAP>(acc, x, w); pair_mfma<OMASK, 7, TAP>(acc, x, w); pair_mfma<OMASK, 8, TAP>(acc, x, w);
 }
+
 template <int OMASK, int I>
-__device__ __forceinline__ void split_cell(SplitA (&a)[CELLS], const float* __restrict__ src, int a0, int a1) {
+__device__ __forceinline__ void load_cell(Pieces (&x)[CELLS], const unsigned char* __restrict__ src, int a0) {
+#ifdef NZ_ABLATE_A   // timing-only build: no LDS reads of the activation operands (outputs are wrong)
+  if constexpr (input_used<OMASK, I>()) { const uint32_t v = 0x3C003C00u + a0 + I; x[I].p[0] = x[I].p[1] = x[I].p[2] = u32x4{v, v, v, v}; asm volatile("" :: "v"(src)); }
+#else
   if constexpr (input_used<OMASK, I>()) {
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(src + a0 + I * (POS * ROW));
-    const f32x4 hi = *reinterpret_cast<const f32x4*>(src + a1 + I * (POS * ROW));
-    split8(lo, hi, a[I]);
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece)
+      x[I].p[piece] = *reinterpret_cast<const u32x4*>(src + piece * PIECE_BYTES + I * (POS * 128) + a0);
   }
+#endif
 }
-__device__ __forceinline__ void load_tap(TapB& t, const float* __restrict__ w, int lane) {
+// this lane's activation operands of K group kg: channels 32 kg + 8 quad .. + 7 of every used input cell
+template <int OMASK>
+__device__ __forceinline__ void load_cells(Pieces (&x)[CELLS], const unsigned char* __restrict__ src, int pos, int quad,
+                                           int kg) {
+  const int a0 = slot_addr(0, pos, kg * 4 + quad);
+  load_cell<OMASK, 0>(x, src, a0); load_cell<OMASK, 1>(x, src, a0); load_cell<OMASK, 2>(x, src, a0);
+  load_cell<OMASK, 3>(x, src, a0); load_cell<OMASK, 4>(x, src, a0); load_cell<OMASK, 5>(x, src, a0);
+  load_cell<OMASK, 6>(x, src, a0); load_cell<OMASK, 7>(x, src, a0); load_cell<OMASK, 8>(x, src, a0);
+}
+__device__ __forceinline__ void load_tap(Pieces& t, const float* __restrict__ w, int lane) {
+#ifdef NZ_ABLATE_B   // timing-only build: no global loads of the weight operands (outputs are wrong)
+  const uint32_t v = 0x3C003C00u + lane;
+  t.p[0] = t.p[1] = t.p[2] = u32x4{v, v, v, v};
+  asm volatile("" :: "v"(w));
+#else
   const u32x4* __restrict__ p = reinterpret_cast<const u32x4*>(w) + lane;
   t.p[0] = p[0];
   t.p[1] = p[64];
   t.p[2] = p[128];
+#endif
 }
 __device__ __forceinline__ void load_b(FragS& f, const float* __restrict__ w, int lane) {   // the first W_RING taps
 #pragma unroll
   for (int i = 0; i < W_RING; ++i) load_tap(f.rb[i], w + i * TAP_DWORDS, lane);
 }
+__device__ __forceinline__ void zero_b(FragS& f) {
+#pragma unroll
+  for (int t = 0; t < W_RING; ++t)
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
+}
+
 // All K groups (32 channels each) of one job, tap-major.  On entry the ring holds the job's first
 // W_RING taps; on exit those of the next job that reads weights (`w_after`, may be null): the
-// weight stream stays W_RING taps ahead, also across jobs and stage barriers.  Per K group the
-// lane reads its 8 channels of every used input cell from LDS (2 x ds_read_b128) and splits them.
+// weight stream stays W_RING taps ahead, also across jobs and stage barriers.  The activation
+// operands of K group kg + 1 are read from LDS while the MFMAs of kg run.
 template <int OMASK>
-__device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, FragS&, const float* __restrict__ src,
+__device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, const unsigned char* __restrict__ src,
                                           const float* __restrict__ w, int kgroups,
                                           const float* __restrict__ w_after, int lane) {
   const int pos = lane & 15, quad = lane >> 4;
   const int n_taps = kgroups * 9;
-  auto refill = [&](TapB& slot, int t) {          // t = stream index of the tap to fetch
+  auto refill = [&](Pieces& slot, int t) {          // t = stream index of the tap to fetch
     if (t < n_taps) load_tap(slot, w + t * TAP_DWORDS, lane);
     else if (w_after != nullptr) load_tap(slot, w_after + (t - n_taps) * TAP_DWORDS, lane);
   };
-  for (int kg = 0; kg < kgroups; ++kg) {
-    const int a0 = act_addr(0, pos, kg * 32 + quad * 8), a1 = act_addr(0, pos, kg * 32 + quad * 8 + 4);
-    SplitA a[CELLS];
-    split_cell<OMASK, 0>(a, src, a0, a1); split_cell<OMASK, 1>(a, src, a0, a1); split_cell<OMASK, 2>(a, src, a0, a1);
-    split_cell<OMASK, 3>(a, src, a0, a1); split_cell<OMASK, 4>(a, src, a0, a1); split_cell<OMASK, 5>(a, src, a0, a1);
-    split_cell<OMASK, 6>(a, src, a0, a1); split_cell<OMASK, 7>(a, src, a0, a1); split_cell<OMASK, 8>(a, src, a0, a1);
+  auto taps = [&](const Pieces (&x)[CELLS], int kg) {
     const int t0 = kg * 9 + W_RING;
-    split_tap<OMASK, 0>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 0);
-    split_tap<OMASK, 1>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 1);
-    split_tap<OMASK, 2>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 2);
-    split_tap<OMASK, 3>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 3);
-    split_tap<OMASK, 4>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 4);
-    split_tap<OMASK, 5>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 5);
-    split_tap<OMASK, 6>(acc, a, f.rb[0]); refill(f.rb[0], t0 + 6);
-    split_tap<OMASK, 7>(acc, a, f.rb[1]); refill(f.rb[1], t0 + 7);
-    split_tap<OMASK, 8>(acc, a, f.rb[2]); refill(f.rb[2], t0 + 8);
+    tap_mfma<OMASK, 0>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 0);
+    tap_mfma<OMASK, 1>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 1);
+    tap_mfma<OMASK, 2>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 2);
+    tap_mfma<OMASK, 3>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 3);
+    tap_mfma<OMASK, 4>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 4);
+    tap_mfma<OMASK, 5>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 5);
+    tap_mfma<OMASK, 6>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 6);
+    tap_mfma<OMASK, 7>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 7);
+    tap_mfma<OMASK, 8>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 8);
+  };
+  if (kgroups <= 0) return;
+  Pieces x0[CELLS], x1[CELLS];
+  load_cells<OMASK>(x0, src, pos, quad, 0);
+  for (int kg = 0; kg < kgroups; kg += 2) {
+    if (kg + 1 < kgroups) load_cells<OMASK>(x1, src, pos, quad, kg + 1);
+    taps(x0, kg);
+    if (kg + 1 < kgroups) {
+      if (kg + 2 < kgroups) load_cells<OMASK>(x0, src, pos, quad, kg + 2);
+      taps(x1, kg + 1);
+    }
   }
 }
 
@@ -290,7 +241,7 @@ template <int OMASK, int TAP, int I>
 __device__ __forceinline__ void mfma_extra_pair(f32x4 (&acc)[CELLS], const float (&ax)[CELLS], const float (&bx)[9]) {
   if constexpr (pair_used<OMASK, I, TAP>()) {
     constexpr int o = TapMap<I, TAP>::o;
-    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[I], bx[TAP], acc[o], 0, 0, 0);
+    acc[o] = __builtin_amdgcn_mfma_f32_16x16x4f32(bx[TAP], ax[I], acc[o], 0, 0, 0);
   }
 }
 template <int OMASK, int TAP>
@@ -301,7 +252,8 @@ __device__ __forceinline__ void mfma_extra_tap(f32x4 (&acc)[CELLS], const float 
   mfma_extra_pair<OMASK, TAP, 6>(acc, ax, bx); mfma_extra_pair<OMASK, TAP, 7>(acc, ax, bx);
   mfma_extra_pair<OMASK, TAP, 8>(acc, ax, bx);
 }
-// the (<= 4) raw input planes as one extra K step (projection / recall conv)
+// the (<= 4) raw input planes as one extra K step in plain float32 (projection / recall conv):
+// lane l supplies W[cout = l & 15][plane = l >> 4] and X[plane = l >> 4][pos = l & 15]
 template <int OMASK>
 __device__ __forceinline__ void extra_planes(f32x4 (&acc)[CELLS], const float* __restrict__ wx,
                                              const float* __restrict__ inp, int lane) {
@@ -315,46 +267,53 @@ __device__ __forceinline__ void extra_planes(f32x4 (&acc)[CELLS], const float* _
   mfma_extra_tap<OMASK, 6>(acc, ax, bx); mfma_extra_tap<OMASK, 7>(acc, ax, bx); mfma_extra_tap<OMASK, 8>(acc, ax, bx);
 }
 
-// ---- epilogues: lane holds C[pos = 4*quad + r][cout = 16*nt + (lane & 15)] for the job's cells ----
-// ACT: 0 none, 1 relu, 2 tanh.  Output cell o lives o*1024 floats after cell 0, so the four
-// per-lane offsets are computed once and every access is base + constant.
+// ---- epilogues: lane holds C[cout = 16 nt + 4 quad + r][pos = lane & 15] for the job's cells ------
+// ACT: 0 none, 1 relu, 2 tanh, 3 elu.  The four channels of a lane are half a 16-byte slot: one
+// ds_write_b64 per piece (and one ds_read_b64 per piece for the residual, which the three pieces
+// reproduce exactly).  Output cell o lives o * 2048 bytes after cell 0.
 template <int OMASK, int ACT, bool RES>
-__device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], float* __restrict__ dst,
-                                             const float* res, int lane, int nt) {
-  const int quad = lane >> 4, cout = nt * 16 + (lane & 15);
-  int off[4];
+__device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], unsigned char* __restrict__ dst,
+                                             const unsigned char* res, int lane, int nt) {
+  const int pos = lane & 15, quad = lane >> 4;
+  const int off = slot_addr(0, pos, nt * 2 + (quad >> 1)) + (quad & 1) * 8;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) off[r] = act_addr(0, quad * 4 + r, cout);
-  float v[CELLS][4];
+  for (int o = 0; o < CELLS; ++o) {
+    if (!((OMASK >> o) & 1)) continue;
+    f32x4 v = acc[o];
+    if constexpr (RES) {                                   // read before the write below (dst may be res)
+      u32x2 q[3];
 #pragma unroll
-  for (int o = 0; o < CELLS; ++o)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (!((OMASK >> o) & 1)) continue;
-      v[o][r] = acc[o][r];
-      if constexpr (RES) v[o][r] += res[o * (POS * ROW) + off[r]];   // read before any write below
+      for (int piece = 0; piece < 3; ++piece)
+        q[piece] = *reinterpret_cast<const u32x2*>(res + piece * PIECE_BYTES + o * (POS * 128) + off);
+      v[0] += (bf16_lo(q[0][0]) + bf16_lo(q[1][0])) + bf16_lo(q[2][0]);
+      v[1] += (bf16_hi(q[0][0]) + bf16_hi(q[1][0])) + bf16_hi(q[2][0]);
+      v[2] += (bf16_lo(q[0][1]) + bf16_lo(q[1][1])) + bf16_lo(q[2][1]);
+      v[3] += (bf16_hi(q[0][1]) + bf16_hi(q[1][1])) + bf16_hi(q[2][1]);
     }
 #pragma unroll
-  for (int o = 0; o < CELLS; ++o)
-#pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (!((OMASK >> o) & 1)) continue;
-      float x = v[o][r];
+      float x = v[r];
       if constexpr (ACT == 1) x = fmaxf(x, 0.0f);
       if constexpr (ACT == 2) x = tanh_fast(x);
       if constexpr (ACT == 3) x = x > 0.0f ? x : expm1f(x);      // nn.ELU(), alpha = 1
-      dst[o * (POS * ROW) + off[r]] = x;
+      v[r] = x;
     }
+    uint32_t a0, a1, a2, b0, b1, b2;
+    split_pair(v[0], v[1], a0, a1, a2);
+    split_pair(v[2], v[3], b0, b1, b2);
+    *reinterpret_cast<u32x2*>(dst + 0 * PIECE_BYTES + o * (POS * 128) + off) = u32x2{a0, b0};
+    *reinterpret_cast<u32x2*>(dst + 1 * PIECE_BYTES + o * (POS * 128) + off) = u32x2{a1, b1};
+    *reinterpret_cast<u32x2*>(dst + 2 * PIECE_BYTES + o * (POS * 128) + off) = u32x2{a2, b2};
+  }
 }
 template <int OMASK>
-__device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob& job, float* __restrict__ lds,
+__device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob& job, unsigned char* __restrict__ lds,
                                          int lane, int policy_channels, int n_valid, float* logits, float* value) {
-  const int quad = lane >> 4;
-  const int cout = job.nt * 16 + (lane & 15);
+  const int pos = lane & 15, quad = lane >> 4;
   if (job.dst < NET_BUFFERS) {
-    float* dst = lds + job.dst * ACT_FLOATS;
+    unsigned char* dst = lds + job.dst * ACT_BYTES;
     if (job.res >= 0) {
-      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 1, true>(acc, dst, lds + job.res * ACT_FLOATS, lane, job.nt);
+      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 1, true>(acc, dst, lds + job.res * ACT_BYTES, lane, job.nt);
     } else if (job.act == 1) {
       epilogue_lds<OMASK, 1, false>(acc, dst, nullptr, lane, job.nt);
     } else if (job.act == 2) {
@@ -364,58 +323,40 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
     } else {
       epilogue_lds<OMASK, 0, false>(acc, dst, nullptr, lane, job.nt);
     }
-  } else if (job.dst == NET_BUFFERS) {        // policy logits [pos][P][9]
-    if (cout < policy_channels) {
+  } else if (job.dst == NET_DST_POLICY) {     // policy logits [pos][P][9]
+    if (pos < n_valid) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gp = quad * 4 + r;
-        if (gp < n_valid) {
+        const int cout = job.nt * 16 + quad * 4 + r;
+        if (cout < policy_channels) {
 #pragma unroll
           for (int o = 0; o < CELLS; ++o)
-            if ((OMASK >> o) & 1) logits[((size_t)gp * policy_channels + cout) * CELLS + o] = acc[o][r];
+            if ((OMASK >> o) & 1) logits[((size_t)pos * policy_channels + cout) * CELLS + o] = acc[o][r];
         }
       }
     }
   } else {                                     // value: mean over (C=1,H,W), tanh (blocks.py:82-84)
     if constexpr (OMASK == 0x1FF) {
-      if (cout == 0) {
+      if (job.nt == 0 && quad == 0 && pos < n_valid) {
+        float s = 0.0f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gp = quad * 4 + r;
-          if (gp < n_valid) {
-            float s = 0.0f;
-#pragma unroll
-            for (int o = 0; o < CELLS; ++o) s += acc[o][r];
-            value[gp] = tanh_fast(s / 9.0f);
-          }
-        }
+        for (int o = 0; o < CELLS; ++o) s += acc[o][0];
+        value[pos] = tanh_fast(s / 9.0f);
       }
     }
   }
 }
 
 // one job: K loop, input-plane step, epilogue
-using NetOperands = typename std::conditional<NET_SPLIT, FragS, Frag>::type;
-__device__ __forceinline__ void zero_b(Frag& f) {
-#pragma unroll
-  for (int t = 0; t < 9; ++t) f.b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-}
-__device__ __forceinline__ void zero_b(FragS& f) {
-#pragma unroll
-  for (int t = 0; t < W_RING; ++t)
-#pragma unroll
-    for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
-}
-
 template <int OMASK, typename Stamp>
-__device__ __forceinline__ void run_job(const NetJob& job, NetOperands& f0, NetOperands& f1, const float* __restrict__ W,
-                                        const float* w_after, float* __restrict__ lds,
+__device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float* __restrict__ W,
+                                        const float* w_after, unsigned char* __restrict__ lds,
                                         const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
                                         float* logits, float* value, Stamp&& stamp) {
   f32x4 acc[CELLS];
 #pragma unroll
   for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-  job_kloop<OMASK>(acc, f0, f1, lds + job.src * ACT_FLOATS, W + job.w_off, job.kgroups, w_after, lane);
+  job_kloop<OMASK>(acc, f, lds + job.src * ACT_BYTES, W + job.w_off, job.kgroups, w_after, lane);
   stamp(0);
   if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
   stamp(1);
@@ -424,26 +365,28 @@ __device__ __forceinline__ void run_job(const NetJob& job, NetOperands& f0, NetO
 }
 
 // Run the compiled network on the 16 positions whose input planes are in `inp`
-// ([cell][pos][4 planes]); `lds` holds the activation buffers.  Every thread of
-// the 256-thread workgroup must call it; it ends with a workgroup barrier.
+// ([cell][pos][4 planes]); `lds_f` holds the activation buffers (NET_BUFFERS * ACT_FLOATS floats,
+// no NaN bit patterns: the callers zero it once).  Every thread of the 256-thread workgroup must
+// call it; it ends with a workgroup barrier.
 // Outputs: logits [pos][policy_channels][9] and value [pos] for pos < n_valid
 // (any address space).
 // STAMPS (diagnostic build only): wave 0 adds up the shader-clock ticks it spends in the K
 // loops, the input-plane step, the epilogues and at the stage barriers into stamps[0..3].
 template <bool STAMPS = false>
 __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, const float* __restrict__ W,
-                                         float* __restrict__ lds, const float* __restrict__ inp,
+                                         float* __restrict__ lds_f, const float* __restrict__ inp,
                                          int policy_channels, int n_valid, float* logits, float* value,
                                          unsigned long long* stamps = nullptr) {
+  unsigned char* __restrict__ lds = reinterpret_cast<unsigned char*>(lds_f);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const NetJob* __restrict__ jobs = prog->jobs[wave];
   const int n_jobs = prog->n_jobs[wave];
 
-  NetOperands f0, f1;
-  zero_b(f0);
-  if (prog->first_w_off[wave] >= 0) load_b(f0, W + prog->first_w_off[wave], lane);
+  FragS f;
+  zero_b(f);
+  if (prog->first_w_off[wave] >= 0) load_b(f, W + prog->first_w_off[wave], lane);
 
   unsigned long long tk[4] = {0, 0, 0, 0}, ts = 0;
   auto stamp = [&](int slot) {
@@ -460,11 +403,11 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
     if (job.og != OG_NONE) {
       const float* w_after = (job.kgroups > 0 && job.next_w_off >= 0) ? W + job.next_w_off : nullptr;
       switch (job.og) {
-        case 0: run_job<og_mask(0)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 1: run_job<og_mask(1)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 2: run_job<og_mask(2)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 3: run_job<og_mask(3)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        default: run_job<og_mask(4)>(job, f0, f1, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 0: run_job<og_mask(0)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        default: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
       }
     }
     stamp(2);
