@@ -37,6 +37,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 matrix peak (dense)
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 
 
@@ -142,6 +143,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": "network: float32 values, every product formed from six bf16 MFMA terms on exact three-way "
+                      "splits, float32 accumulation (as accurate as a float32 convolution, DESIGN.md section 4); "
+                      "tree statistics float64",
         "config": {"workload": "Tic_Tac_Toe, %d sims/move, %d concurrent self-play games per GPU (%d games per "
                                "round), RecurrentNet(2,1,64,2) %d recurrent iterations f32, tree statistics f64, "
                                "legacy TTT search config" % (args.sims, args.games, n_round, args.iters),
@@ -153,6 +157,15 @@ def main():
 
     if not args.no_extras:
         flops_pos = eng.net_flops_per_position()
+        bf16_pos, f32_pos = eng.net_matrix_flops_per_position()
+
+        def executed(tflops_algorithmic):
+            """The same time priced by the MFMA instructions actually issued."""
+            scale = tflops_algorithmic / flops_pos
+            return {"bf16_mfma_tflops": scale * bf16_pos, "bf16_mfma_peak": MFMA_BF16_PEAK_TFLOPS,
+                    "bf16_mfma_frac": scale * bf16_pos / MFMA_BF16_PEAK_TFLOPS,
+                    "f32_mfma_tflops": scale * f32_pos,
+                    "matrix_flops_per_position": {"bf16": bf16_pos, "f32": f32_pos}}
         # ---- dominant kernel: HIP events around the persistent kernel, on its own stream, one more round
         eng.profile(True)
         eng.play(base_seed=10 ** 6 + rank * n_round)
@@ -172,8 +185,10 @@ def main():
             "bound": "mfma", "kernel": "selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
             "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+            "peak_note": "float32 dense MFMA peak: what a kernel doing this float32 arithmetic on the FP32 matrix "
+                         "cores could reach; the kernel issues bf16 MFMAs instead, see `executed`",
             "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(k_n, 1),
-            "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n}
+            "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n, "executed": executed(achieved)}
     if not args.no_extras and world == 1:
         # ---- in-kernel phase shares (stamped diagnostic build; its run time is not quoted)
         eng.phase_stamps(True)
@@ -192,7 +207,7 @@ def main():
         out["roofline_net"] = {"bound": "mfma", "kernel": "net_kernel (fused RecurrentNet forward, 4096 positions)",
                                "achieved": net_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": net_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                               "avg_launch_us": pn["ms"] * 1e3 / 20}
+                               "avg_launch_us": pn["ms"] * 1e3 / 20, "executed": executed(net_tf)}
         # ---- the tree kernel alone against HBM (SURVEY.md 8d bytes: 11 + 20 k per scored node, 24 per
         #      path node backed up): lock-step route with a table evaluator, so advance_kernel does a whole
         #      move's select/expand/backup per launch; at the workload's 4096 trees and at 65536 trees

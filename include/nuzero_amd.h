@@ -219,6 +219,11 @@ nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream);
 /* Algorithmic FLOPs of one network evaluation (one position): sum over convs of
  * 2 * C_out * C_in * 49, i.e. only the taps that fall inside the 3x3 board. */
 nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host);
+/* What the matrix cores execute per position for it: the fused kernel forms each float32
+ * product from six bf16 MFMA terms on exact three-way splits (bf16_flops, including the
+ * zero-padded channels of 32-channel K groups) and uses float32 MFMAs for the raw input
+ * planes (f32_flops). */
+nz_status nz_engine_net_matrix_flops(const nz_engine* e, double* bf16_flops_host, double* f32_flops_host);
 
 /* ---- stand-alone operators (same kernels, callable by themselves) ---------
  * Network_Manager.inference for a batch (Network_Manager.py:46-64):

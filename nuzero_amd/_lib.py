@@ -81,6 +81,7 @@ SIGNATURES = {
     "nz_engine_counters": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "nz_engine_counters_ex": (c_int32, [c_void_p, POINTER(c_int64), c_void_p]),
     "nz_engine_net_flops": (c_int32, [c_void_p, POINTER(c_double)]),
+    "nz_engine_net_matrix_flops": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "nz_net_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_net_forward_stamps": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, POINTER(c_double)]),
     "nz_engine_profile": (c_int32, [c_void_p, c_int32]),

@@ -44,6 +44,7 @@ struct nz_engine {
   float* table_dev = nullptr;
   float* leaf_logits = nullptr;
   float* leaf_value = nullptr;
+  double executed_bf16_flops_per_position = 0.0, executed_f32_flops_per_position = 0.0;
   double algorithmic_flops_per_position = 0.0;
   // host staging for nz_engine_play
   int32_t* h_children = nullptr;   // pinned [G]
@@ -506,6 +507,20 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
     pg.first_w_off[w] = next;
   }
   e->algorithmic_flops_per_position = flops;
+  {   // what the matrix cores execute for one tile of 16 positions (net_dev.hpp): six bf16 MFMAs per
+      // (input cell, tap) pair and 32-channel K group, one float32 MFMA per pair for the input planes
+    static const int og_taps[5] = {49, 13, 12, 12, 12};
+    double bf16 = 0.0, f32 = 0.0;
+    for (int w = 0; w < NET_WAVES_HOST; ++w)
+      for (int j = 0; j < pg.n_jobs[w]; ++j) {
+        const NetJob& job = pg.jobs[w][j];
+        if (job.og == OG_NONE) continue;
+        bf16 += (double)og_taps[job.og] * job.kgroups * 6.0 * (2.0 * 16 * 16 * 32);
+        f32 += (double)og_taps[job.og] * job.extra * (2.0 * 16 * 16 * 4);
+      }
+    e->executed_bf16_flops_per_position = bf16 / 16.0;
+    e->executed_f32_flops_per_position = f32 / 16.0;
+  }
 
   if (e->weights_dev) { (void)hipFree(e->weights_dev); e->weights_dev = nullptr; }
   NZ_HIP(e, hipMalloc((void**)&e->weights_dev, packed.size() * sizeof(float)));
@@ -929,6 +944,13 @@ nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream) 
 nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host) {
   if (!e || !flops_host) return NZ_ERR_ARG;
   *flops_host = e->algorithmic_flops_per_position;
+  return NZ_OK;
+}
+
+nz_status nz_engine_net_matrix_flops(const nz_engine* e, double* bf16_flops_host, double* f32_flops_host) {
+  if (!e || !bf16_flops_host || !f32_flops_host) return NZ_ERR_ARG;
+  *bf16_flops_host = e->executed_bf16_flops_per_position;
+  *f32_flops_host = e->executed_f32_flops_per_position;
   return NZ_OK;
 }
 

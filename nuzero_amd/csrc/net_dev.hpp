@@ -41,9 +41,9 @@
 // (engine.hip): a job is one (layer, 16-channel output tile, output-cell group).
 // 64-channel layers give each of the 4 waves one full tile; the narrow head layers are cut
 // by output-cell group as well so that all four matrix pipes stay busy.  Per 32-channel K
-// group a wave reads 3 x 16 bytes per used input cell from LDS (the next K group's while
-// the MFMAs of this one run) and streams the weights tap by tap from L2, three taps ahead
-// of the MFMAs -- also across jobs and stage barriers.
+// group a wave reads 3 x 16 bytes per used input cell from LDS (refilled in place for the next
+// K group as soon as the last tap that needs a cell has issued) and streams the weights tap by
+// tap from L2, one whole K group ahead of the MFMAs -- also across jobs and stage barriers.
 //
 // LDS layout: act[buffer][piece][cell][pos][64 ch] bf16, the 16-byte slot index XOR-ed with
 // (pos >> 1) & 7 so that ds_read_b128 (operands) and ds_write_b64 (epilogue) are
@@ -70,7 +70,7 @@ constexpr int ACT_FLOATS = ACT_BYTES / 4;                   // LDS is declared a
 constexpr int INP_FLOATS = CELLS * POS * 4;
 constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
 constexpr int TAP_DWORDS = 3 * 64 * 4;                      // one tap of one K group: [piece][lane][8 bf16]
-constexpr int W_RING = 3;                                   // taps in flight; 9 taps per K group keep the slots aligned
+constexpr int W_RING = 9;                                   // taps in flight: the weights run one whole K group ahead
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
 static_assert(NET_KG_DWORDS == 9 * TAP_DWORDS && NET_KG_CHANNELS == 32, "host packing (engine.hip) and kernel agree");
 
@@ -140,6 +140,10 @@ __device__ __forceinline__ void pair_mfma(f32x4 (&acc)[CELLS], const Pieces (&x)
     acc[o] = mfma_bf16(w.p[0], x[I].p[1], acc[o]);
     acc[o] = mfma_bf16(w.p[1], x[I].p[0], acc[o]);
     acc[o] = mfma_bf16(w.p[0], x[I].p[0], acc[o]);
+    // keep the chain together: the scheduler would interleave it with the other pairs' chains, and
+    // round-robin over accumulators issues at 21 cycles per MFMA instead of 16
+    // (scripts/microbench/mfma_bf16_rate.hip)
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 // all (input cell, TAP) pairs of the job's output cells: independent accumulators
@@ -183,7 +187,7 @@ __device__ __forceinline__ void load_tap(Pieces& t, const float* __restrict__ w,
   t.p[2] = p[128];
 #endif
 }
-__device__ __forceinline__ void load_b(FragS& f, const float* __restrict__ w, int lane) {   // the first W_RING taps
+__device__ __forceinline__ void load_b(FragS& f, const float* __restrict__ w, int lane) {   // a whole K group
 #pragma unroll
   for (int i = 0; i < W_RING; ++i) load_tap(f.rb[i], w + i * TAP_DWORDS, lane);
 }
@@ -194,42 +198,44 @@ __device__ __forceinline__ void zero_b(FragS& f) {
     for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
 }
 
-// All K groups (32 channels each) of one job, tap-major.  On entry the ring holds the job's first
-// W_RING taps; on exit those of the next job that reads weights (`w_after`, may be null): the
-// weight stream stays W_RING taps ahead, also across jobs and stage barriers.  The activation
-// operands of K group kg + 1 are read from LDS while the MFMAs of kg run.
-template <int OMASK>
+// One K group (32 channels), tap-major: tap t's MFMAs, then slot t of the weight ring is refilled
+// with tap t of the NEXT K group (`wn`, may be null) -- the weight stream runs one K group (~4,700
+// MFMA cycles) ahead, also across jobs and stage barriers.  With MORE the activation operands are
+// refilled in place for the next K group (LDS slot address a1) after the last tap that reads
+// them: cell 0 after tap 4, cells 1-2 after tap 5, 3 and 6 after tap 7, the rest after tap 8.
+template <int OMASK, bool MORE>
+__device__ __forceinline__ void kgroup(f32x4 (&acc)[CELLS], Pieces (&x)[CELLS], FragS& f,
+                                       const unsigned char* __restrict__ src, int a1,
+                                       const float* __restrict__ wn, int lane) {
+  tap_mfma<OMASK, 0>(acc, x, f.rb[0]); if (wn != nullptr) load_tap(f.rb[0], wn + 0 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 1>(acc, x, f.rb[1]); if (wn != nullptr) load_tap(f.rb[1], wn + 1 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 2>(acc, x, f.rb[2]); if (wn != nullptr) load_tap(f.rb[2], wn + 2 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 3>(acc, x, f.rb[3]); if (wn != nullptr) load_tap(f.rb[3], wn + 3 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 4>(acc, x, f.rb[4]); if (wn != nullptr) load_tap(f.rb[4], wn + 4 * TAP_DWORDS, lane);
+  if constexpr (MORE) load_cell<OMASK, 0>(x, src, a1);
+  tap_mfma<OMASK, 5>(acc, x, f.rb[5]); if (wn != nullptr) load_tap(f.rb[5], wn + 5 * TAP_DWORDS, lane);
+  if constexpr (MORE) { load_cell<OMASK, 1>(x, src, a1); load_cell<OMASK, 2>(x, src, a1); }
+  tap_mfma<OMASK, 6>(acc, x, f.rb[6]); if (wn != nullptr) load_tap(f.rb[6], wn + 6 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 7>(acc, x, f.rb[7]); if (wn != nullptr) load_tap(f.rb[7], wn + 7 * TAP_DWORDS, lane);
+  if constexpr (MORE) { load_cell<OMASK, 3>(x, src, a1); load_cell<OMASK, 6>(x, src, a1); }
+  tap_mfma<OMASK, 8>(acc, x, f.rb[8]); if (wn != nullptr) load_tap(f.rb[8], wn + 8 * TAP_DWORDS, lane);
+  if constexpr (MORE) { load_cell<OMASK, 4>(x, src, a1); load_cell<OMASK, 5>(x, src, a1); load_cell<OMASK, 7>(x, src, a1); load_cell<OMASK, 8>(x, src, a1); }
+}
+// All K groups of one job as straight-line code (KG = 1 or 2: layers are at most 64 channels wide;
+// a loop would carry the operand registers around its back edge through copies).  On entry the
+// ring holds the taps of the job's first K group; on exit those of the next job that reads
+// weights (`w_after`, may be null).
+template <int OMASK, int KG>
 __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, const unsigned char* __restrict__ src,
-                                          const float* __restrict__ w, int kgroups,
-                                          const float* __restrict__ w_after, int lane) {
+                                          const float* __restrict__ w, const float* __restrict__ w_after, int lane) {
   const int pos = lane & 15, quad = lane >> 4;
-  const int n_taps = kgroups * 9;
-  auto refill = [&](Pieces& slot, int t) {          // t = stream index of the tap to fetch
-    if (t < n_taps) load_tap(slot, w + t * TAP_DWORDS, lane);
-    else if (w_after != nullptr) load_tap(slot, w_after + (t - n_taps) * TAP_DWORDS, lane);
-  };
-  auto taps = [&](const Pieces (&x)[CELLS], int kg) {
-    const int t0 = kg * 9 + W_RING;
-    tap_mfma<OMASK, 0>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 0);
-    tap_mfma<OMASK, 1>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 1);
-    tap_mfma<OMASK, 2>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 2);
-    tap_mfma<OMASK, 3>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 3);
-    tap_mfma<OMASK, 4>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 4);
-    tap_mfma<OMASK, 5>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 5);
-    tap_mfma<OMASK, 6>(acc, x, f.rb[0]); refill(f.rb[0], t0 + 6);
-    tap_mfma<OMASK, 7>(acc, x, f.rb[1]); refill(f.rb[1], t0 + 7);
-    tap_mfma<OMASK, 8>(acc, x, f.rb[2]); refill(f.rb[2], t0 + 8);
-  };
-  if (kgroups <= 0) return;
-  Pieces x0[CELLS], x1[CELLS];
-  load_cells<OMASK>(x0, src, pos, quad, 0);
-  for (int kg = 0; kg < kgroups; kg += 2) {
-    if (kg + 1 < kgroups) load_cells<OMASK>(x1, src, pos, quad, kg + 1);
-    taps(x0, kg);
-    if (kg + 1 < kgroups) {
-      if (kg + 2 < kgroups) load_cells<OMASK>(x0, src, pos, quad, kg + 2);
-      taps(x1, kg + 1);
-    }
+  Pieces x[CELLS];
+  load_cells<OMASK>(x, src, pos, quad, 0);
+  if constexpr (KG == 2) {
+    kgroup<OMASK, true>(acc, x, f, src, slot_addr(0, pos, 4 + quad), w + NET_KG_DWORDS, lane);
+    kgroup<OMASK, false>(acc, x, f, src, 0, w_after, lane);
+  } else {
+    kgroup<OMASK, false>(acc, x, f, src, 0, w_after, lane);
   }
 }
 
@@ -276,19 +282,23 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], unsigned
                                              const unsigned char* res, int lane, int nt) {
   const int pos = lane & 15, quad = lane >> 4;
   const int off = slot_addr(0, pos, nt * 2 + (quad >> 1)) + (quad & 1) * 8;
+  u32x2 q[CELLS][3];
+  if constexpr (RES) {                                     // all residual reads in flight at once, before any write
+#pragma unroll
+    for (int o = 0; o < CELLS; ++o)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece)
+        if ((OMASK >> o) & 1) q[o][piece] = *reinterpret_cast<const u32x2*>(res + piece * PIECE_BYTES + o * (POS * 128) + off);
+  }
 #pragma unroll
   for (int o = 0; o < CELLS; ++o) {
     if (!((OMASK >> o) & 1)) continue;
     f32x4 v = acc[o];
-    if constexpr (RES) {                                   // read before the write below (dst may be res)
-      u32x2 q[3];
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece)
-        q[piece] = *reinterpret_cast<const u32x2*>(res + piece * PIECE_BYTES + o * (POS * 128) + off);
-      v[0] += (bf16_lo(q[0][0]) + bf16_lo(q[1][0])) + bf16_lo(q[2][0]);
-      v[1] += (bf16_hi(q[0][0]) + bf16_hi(q[1][0])) + bf16_hi(q[2][0]);
-      v[2] += (bf16_lo(q[0][1]) + bf16_lo(q[1][1])) + bf16_lo(q[2][1]);
-      v[3] += (bf16_hi(q[0][1]) + bf16_hi(q[1][1])) + bf16_hi(q[2][1]);
+    if constexpr (RES) {
+      v[0] += (bf16_lo(q[o][0][0]) + bf16_lo(q[o][1][0])) + bf16_lo(q[o][2][0]);
+      v[1] += (bf16_hi(q[o][0][0]) + bf16_hi(q[o][1][0])) + bf16_hi(q[o][2][0]);
+      v[2] += (bf16_lo(q[o][0][1]) + bf16_lo(q[o][1][1])) + bf16_lo(q[o][2][1]);
+      v[3] += (bf16_hi(q[o][0][1]) + bf16_hi(q[o][1][1])) + bf16_hi(q[o][2][1]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -356,7 +366,8 @@ __device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float
   f32x4 acc[CELLS];
 #pragma unroll
   for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
-  job_kloop<OMASK>(acc, f, lds + job.src * ACT_BYTES, W + job.w_off, job.kgroups, w_after, lane);
+  if (job.kgroups == 2) job_kloop<OMASK, 2>(acc, f, lds + job.src * ACT_BYTES, W + job.w_off, w_after, lane);
+  else if (job.kgroups == 1) job_kloop<OMASK, 1>(acc, f, lds + job.src * ACT_BYTES, W + job.w_off, w_after, lane);
   stamp(0);
   if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
   stamp(1);

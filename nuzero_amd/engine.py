@@ -107,6 +107,12 @@ class SelfPlayEngine:
         check(lib.nz_engine_net_flops(self._h, byref(v)), self._h)
         return v.value
 
+    def net_matrix_flops_per_position(self):
+        """(bf16, f32) FLOPs the matrix cores execute per position (six split terms per float32 product)."""
+        a, b = c_double(0), c_double(0)
+        check(lib.nz_engine_net_matrix_flops(self._h, byref(a), byref(b)), self._h)
+        return a.value, b.value
+
     def net_forward(self, states, want_probs=True):
         """Network_Manager.inference for a float32 [B, 2, 3, 3] batch on the GPU.
         Returns (logits [B, 9], value [B], probs [B, 9] or None)."""
