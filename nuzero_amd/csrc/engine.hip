@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <algorithm>
 #include <string>
@@ -337,6 +338,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   p.eps_softmax = cfg->epsilon_softmax_exploration;
   p.eps_random = cfg->epsilon_random_exploration;
   p.sims_per_cycle = 16;
+  if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
 
   // Explorer.calculate_exploration_bias / calculate_ucb_factor (Explorer.py:103-112):
   // log() and sqrt() of the parent visit count, from the host libm
