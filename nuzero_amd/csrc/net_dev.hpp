@@ -418,10 +418,8 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   };
   if constexpr (STAMPS) ts = __builtin_amdgcn_s_memtime();
 
-  NetJob next_job = jobs[0];
   for (int j = 0; j < n_jobs; ++j) {
-    const NetJob job = next_job;
-    if (j + 1 < n_jobs) next_job = jobs[j + 1];      // the descriptor's scalar loads fly under this job's MFMAs
+    const NetJob job = jobs[j];
     if (job.og != OG_NONE) {
       const float* w_after = (job.kgroups > 0 && job.next_w_off >= 0) ? W + job.next_w_off : nullptr;
       switch (job.og) {
