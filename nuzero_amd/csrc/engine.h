@@ -72,6 +72,8 @@ struct TreeParams {
   int32_t softmax_moves;
   double eps_softmax, eps_random;
   int32_t sims_per_cycle;  // persistent kernel: simulations a game may run between two network passes
+  int32_t max_cycles;      // persistent kernel: tree/network cycles a workgroup may run before it gives up
+                           // (error flag 64) -- a bound every wave reaches, whatever goes wrong
   int32_t* error_flag;
   // per-move records, [G][T]...
   uint32_t* hist_board;

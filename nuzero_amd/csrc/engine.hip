@@ -247,7 +247,8 @@ nz_status check_device_flag(nz_engine* e, hipStream_t s) {
   NZ_HIP(e, hipStreamSynchronize(s));
   if (flag != 0)
     return fail(e, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 = tree arena full, 2 = visit table too short, "
-                                    "4 = move finished before its search, 8 = forced action is not legal)", flag);
+                                    "4 = move finished before its search, 8 = forced action is not legal, "
+                                    "64 = persistent kernel gave up after its cycle bound)", flag);
   return NZ_OK;
 }
 
@@ -339,6 +340,11 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   p.eps_random = cfg->epsilon_random_exploration;
   p.sims_per_cycle = 16;
   if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
+  {   // every cycle finishes at least one simulation or one move of every live row of the workgroup
+    const double games_per_slot = std::ceil((double)p.n_games / (double)p.n_slots) + 2.0;
+    const double bound = 16.0 * games_per_slot * TTT_MAX_MOVES * ((double)cfg->mcts_simulations + 2.0);
+    p.max_cycles = (int32_t)std::min(bound, 2.0e9);
+  }
 
   // Explorer.calculate_exploration_bias / calculate_ucb_factor (Explorer.py:103-112):
   // log() and sqrt() of the parent visit count, from the host libm

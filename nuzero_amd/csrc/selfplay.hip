@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
 
   __shared__ int s_max_sims;
   unsigned long long crit_sims = 0;
+  int cycle = 0;
   for (;;) {
     // ------------------------------ tree phase ---------------------------------
     int cyc_sims = 0;
@@ -217,6 +218,10 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       crit_sims += (unsigned long long)s_max_sims;
     }
     if (!any_alive) break;
+    if (++cycle > p.max_cycles) {     // uniform over the workgroup: never spin forever
+      if (tid == 0) atomicOr(p.error_flag, 64);
+      break;
+    }
     if (!any_pending) continue;       // every live row used up its simulations for this cycle
 
     // ------------------------------ net phase ----------------------------------
