@@ -7,6 +7,11 @@ available, so the hex form cannot run or be pinned) -- either by the hand-writte
 (nz_boardnet_*, --evaluator native) or by PyTorch/MIOpen (--evaluator torch).
 
     python bench_scs.py [--games 1024] [--sims 200] [--filters 32] [--layers 8] [--evaluator native|torch]
+
+Several GPUs (weak scaling, --games per GPU; games are independent, so each rank plays its own shard with its own
+engine and the finished games are gathered on rank 0 with one RCCL gather per round):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench_scs.py --gpus N
 """
 import argparse
 import json
@@ -49,7 +54,8 @@ def cpu_baseline(config_path, weights, layers, search, seconds):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--games", type=int, default=1024)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=200)
     ap.add_argument("--filters", type=int, default=32)
     ap.add_argument("--layers", type=int, default=8)
@@ -63,6 +69,13 @@ def main():
     args = ap.parse_args()
     import torch
     import torch.nn.functional as F
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from nuzero_amd import dist as nzdist
     from nuzero_amd.boardnet import BoardNet
     from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
     from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
@@ -71,7 +84,7 @@ def main():
     w = synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, args.filters, args.layers))
     if args.evaluator == "native":
         net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
-                       num_blocks=args.layers, kernel_size=3, max_batch=args.games)
+                       num_blocks=args.layers, kernel_size=3, max_batch=args.games, device=local)
         net.set_weights(w)
         ev = net.evaluator()
     else:
@@ -101,16 +114,34 @@ def main():
                               "epsilon_random_exploration": 0.001, "value_factor": 1,
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
-    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * args.nodes_per_sim)
+    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * args.nodes_per_sim, device=local)
+    seeds = range(rank * args.games, (rank + 1) * args.games)       # game index = rank * games + g
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
     t0 = time.perf_counter()
     if args.evaluator == "native" and args.loop == "library":
-        r = sp.play_native(net, range(args.games))
+        r = sp.play_native(net, seeds)
     else:
-        r = sp.play(ev, seeds=range(args.games))
+        r = sp.play(ev, seeds=seeds)
+    if world > 1:                                  # the round's games to rank 0's replay buffer
+        nzdist.gather_payload(nzdist.scs_payload(r, torch.device("cuda", local)), world, rank, 0, nzdist.SCS_FIELDS)
     torch.cuda.synchronize()
+    if world > 1:
+        td.barrier()
     dt = time.perf_counter() - t0
+    totals = torch.tensor([dt, float(args.games), float(r["expansions"]), float(r["simulations"])], dtype=torch.float64,
+                          device="cuda")
+    if world > 1:
+        tmax = totals.clone()
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        td.all_reduce(totals, op=td.ReduceOp.SUM)
+        totals[0] = tmax[0]
+    dt, n_games, n_exp, n_sim = [float(v) for v in totals.cpu()]
+    if rank != 0:
+        td.destroy_process_group()
+        return
     out = {}
     if args.cpu_seconds > 0:
         base = cpu_baseline(args.config, w, args.layers, search, args.cpu_seconds)
@@ -120,11 +151,13 @@ def main():
                                   "square convs), %s evaluator, %s move loop" % (
                                       cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, args.filters, args.layers,
                                       args.evaluator, args.loop if args.evaluator == "native" else "python"),
-                      "waves": r.get("waves"),
-                      "games_per_s": args.games / dt, "expansions_per_s": r["expansions"] / dt,
-                      "simulations_per_s": r["simulations"] / dt, "seconds": dt,
+                      "waves": r.get("waves"), "n_gpus": world, "scaling": "weak",
+                      "games_per_s": n_games / dt, "expansions_per_s": n_exp / dt,
+                      "simulations_per_s": n_sim / dt, "seconds": dt,
                       "mean_game_length": float(r["lengths"].mean()),
                       "outcomes": {str(v): int((r["outcomes"] == v).sum()) for v in (-1, 0, 1)}, **out}))
+    if world > 1:
+        td.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -117,6 +117,53 @@ def test_gather_world_size_2_gloo():
     assert ret.get("ok") is True and ret.get("none1") is True
 
 
+def _scs_result(rank, n=5):
+    rs = np.random.RandomState(100 + rank)
+    return {"lengths": rs.randint(10, 60, n).astype(np.int32), "outcomes": rs.randint(-1, 2, n).astype(np.int32),
+            "actions": rs.randint(-1, 525, (n, 256)).astype(np.int32), "n_children": rs.randint(0, 40, (n, 256)).astype(np.int32),
+            "child_action": rs.randint(0, 525, (n, 256, 64)).astype(np.int32),
+            "child_visit": rs.randint(0, 200, (n, 256, 64)).astype(np.int32),
+            "bias": rs.random_sample((n, 256))}            # not part of the gathered fields
+
+
+def _scs_gather_worker(rank, world, port, ret):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    from nuzero_amd import dist as nzdist
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        got = nzdist.gather_payload(nzdist.scs_payload(_scs_result(rank)), world, rank, dst=0, fields=nzdist.SCS_FIELDS)
+        if rank == 0:
+            ok = set(got.keys()) == set(nzdist.SCS_FIELDS)
+            for k in nzdist.SCS_FIELDS:
+                want = np.concatenate([_scs_result(r)[k] for r in range(world)], 0)
+                ok = ok and np.array_equal(got[k].numpy(), want)
+            ret["ok"] = ok
+        else:
+            ret[f"none{rank}"] = got is None
+    finally:
+        td.destroy_process_group()
+
+
+def test_scs_gather_world_size_2_gloo():
+    """SCS rounds shard by game like Tic-Tac-Toe rounds: one gather of moves and policy targets per round."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_scs_gather_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get("ok") is True and ret.get("none1") is True
+
+
 def test_game_record_contract():
     """What ReplayBuffer.save_game and AlphaZero.batch_update_weights touch."""
     from nuzero_amd.gamer import GameRecord, game_stats
