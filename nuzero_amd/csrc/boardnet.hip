@@ -360,9 +360,13 @@ void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
   } else if (ntiles % 3 == 0) {
     launch_conv<1, 3, 4>(a, ntiles, s);
   } else if (ntiles % 2 == 0) {
-    launch_conv<1, 2, 4>(a, ntiles, s);
+    const int mt = force_mt ? force_mt : a.n_host >= 2048 ? 2 : 1;      // + 7 % at 2048 and 8192 positions; MT = 4 loses
+    if (mt >= 2) launch_conv<2, 2, 3>(a, ntiles, s);
+    else launch_conv<1, 2, 4>(a, ntiles, s);
   } else {
-    launch_conv<1, 1, 4>(a, ntiles, s);
+    const int mt = force_mt ? force_mt : a.n_host >= 2048 ? 2 : 1;
+    if (mt >= 2) launch_conv<2, 1, 3>(a, ntiles, s);
+    else launch_conv<1, 1, 4>(a, ntiles, s);
   }
 }
 }  // namespace
