@@ -57,8 +57,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--games", type=int, default=1024, help="concurrent games per GPU")
     ap.add_argument("--sims", type=int, default=200)
+    ap.add_argument("--arch", choices=["convnet", "resnet", "recurrent"], default="convnet")
     ap.add_argument("--filters", type=int, default=32)
-    ap.add_argument("--layers", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=8, help="ConvNet layers / ResNet or RecurrentNet blocks")
+    ap.add_argument("--iters", type=int, default=1, help="recurrent iterations (RecurrentNet)")
     ap.add_argument("--evaluator", choices=["native", "torch"], default="native")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
@@ -78,16 +80,29 @@ def main():
     from nuzero_amd import dist as nzdist
     from nuzero_amd.boardnet import BoardNet
     from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
-    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    from nuzero_amd.weights import (synthetic_weights, convnet_param_shapes, resnet_param_shapes,
+                                    recurrent_net_param_shapes)
     cfg = ScsGameConfig(args.config)
-    # ConvNet(in, policy, kernel_size=3, num_filters, num_layers, hex=False) with random-init weights
-    w = synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, args.filters, args.layers))
+    # the reference's nets with hex=False and random-init weights: ConvNet(in, policy, 3, filters, layers),
+    # ResNet(in, policy, filters, blocks), RecurrentNet(in, policy, filters, blocks, recall=True)
+    if args.arch == "convnet":
+        shapes = convnet_param_shapes(cfg.channels, cfg.planes, 3, args.filters, args.layers)
+    elif args.arch == "resnet":
+        shapes = resnet_param_shapes(cfg.channels, cfg.planes, args.filters, args.layers)
+    else:
+        shapes = recurrent_net_param_shapes(cfg.channels, cfg.planes, args.filters, args.layers, True)
+    w = synthetic_weights(0, shapes)
+    net_name = {"convnet": "ConvNet(%d filters, %d layers", "resnet": "ResNet(%d filters, %d blocks",
+                "recurrent": "RecurrentNet(%d filters, %d blocks"}[args.arch] % (args.filters, args.layers)
+    if args.arch == "recurrent":
+        net_name += ", %d iterations" % args.iters
     if args.evaluator == "native":
-        net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
+        net = BoardNet(args.arch, cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
                        num_blocks=args.layers, kernel_size=3, max_batch=args.games, device=local)
-        net.set_weights(w)
+        net.set_weights(w, args.iters)
         ev = net.evaluator()
     else:
+        assert args.arch == "convnet", "the PyTorch comparison path is written for ConvNet"
         torch.backends.cudnn.benchmark = True        # let MIOpen pick a solver for the (fixed) leaf-batch shape
         wd = {k: torch.from_numpy(v).cuda() for k, v in w.items()}
         conv = lambda t, name: F.conv2d(t, wd[name], None, 1, "same")
@@ -144,13 +159,16 @@ def main():
         return
     out = {}
     if args.cpu_seconds > 0:
+        assert args.arch == "convnet", "the CPU baseline is written for ConvNet"
         base = cpu_baseline(args.config, w, args.layers, search, args.cpu_seconds)
         base["games_per_s_estimate"] = base["moves_per_s"] / float(r["lengths"].mean())
         out["cpu_baseline"] = base
-    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, ConvNet(%d filters, %d layers, "
-                                  "square convs), %s evaluator, %s move loop" % (
-                                      cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, args.filters, args.layers,
-                                      args.evaluator, args.loop if args.evaluator == "native" else "python"),
+    native = args.evaluator == "native"
+    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, square convs), %s evaluator, "
+                                  "%s move loop" % (cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, net_name,
+                                                    args.evaluator, args.loop if native else "python"),
+                      "net_flops_per_position": net.flops_per_position if native else None,
+                      "net_tflops": n_exp * net.flops_per_position / dt / 1e12 if native else None,
                       "waves": r.get("waves"), "n_gpus": world, "scaling": "weak",
                       "games_per_s": n_games / dt, "expansions_per_s": n_exp / dt,
                       "simulations_per_s": n_sim / dt, "seconds": dt,
