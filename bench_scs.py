@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--filters", type=int, default=32)
     ap.add_argument("--layers", type=int, default=8, help="ConvNet layers / ResNet or RecurrentNet blocks")
     ap.add_argument("--iters", type=int, default=1, help="recurrent iterations (RecurrentNet)")
+    ap.add_argument("--hex", action="store_true", help="hex=True nets (hexagdly.Conv2d(kernel_size=1) everywhere; parity "
+                                                        "unpinned: hexagdly is not installed), native evaluator only")
     ap.add_argument("--evaluator", choices=["native", "torch"], default="native")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
@@ -91,6 +93,10 @@ def main():
         shapes = resnet_param_shapes(cfg.channels, cfg.planes, args.filters, args.layers)
     else:
         shapes = recurrent_net_param_shapes(cfg.channels, cfg.planes, args.filters, args.layers, True)
+    if args.hex:
+        from nuzero_amd.weights import hex_param_shapes
+        assert args.evaluator == "native", "--hex needs the native evaluator"
+        shapes = hex_param_shapes(shapes)
     w = synthetic_weights(0, shapes)
     net_name = {"convnet": "ConvNet(%d filters, %d layers", "resnet": "ResNet(%d filters, %d blocks",
                 "recurrent": "RecurrentNet(%d filters, %d blocks"}[args.arch] % (args.filters, args.layers)
@@ -98,7 +104,7 @@ def main():
         net_name += ", %d iterations" % args.iters
     if args.evaluator == "native":
         net = BoardNet(args.arch, cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
-                       num_blocks=args.layers, kernel_size=3, max_batch=args.games, device=local)
+                       num_blocks=args.layers, kernel_size=3, max_batch=args.games, device=local, hex=args.hex)
         net.set_weights(w, args.iters)
         ev = net.evaluator()
     else:
@@ -164,8 +170,9 @@ def main():
         base["games_per_s_estimate"] = base["moves_per_s"] / float(r["lengths"].mean())
         out["cpu_baseline"] = base
     native = args.evaluator == "native"
-    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, square convs), %s evaluator, "
+    print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, %s convs), %s evaluator, "
                                   "%s move loop" % (cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, net_name,
+                                                    "hexagonal (unpinned)" if args.hex else "square",
                                                     args.evaluator, args.loop if native else "python"),
                       "net_flops_per_position": net.flops_per_position if native else None,
                       "net_tflops": n_exp * net.flops_per_position / dt / 1e12 if native else None,

@@ -65,7 +65,7 @@ typedef struct nz_game_desc {
   int32_t negate_player;                /* Q is negated iff parent.to_play == this (Explorer.py:124) */
 } nz_game_desc;
 
-/* The square-conv (hex=False) policy/value networks of the reference, all with the
+/* The policy/value networks of the reference (square convs; hexagonal ones for nz_boardnet_*), all with the
  * "conv" policy head and the "reduce" value head (blocks.py:46-92,130-170):
  *   NZ_ARCH_RECURRENT  RecurrentNet(in_channels, policy_channels, num_filters=width, num_blocks,
  *                      recall, value_activation)   (Architectures/RecurrentNet.py:18-99)
@@ -82,7 +82,12 @@ typedef struct nz_net_desc {
   int32_t recall;                       /* RecurrentNet only */
   int32_t value_activation;             /* NZ_ACT_* */
   int32_t arch;                         /* NZ_ARCH_* */
-  int32_t kernel_size;                  /* ConvNet trunk: 1 or 3; others: 3 */
+  int32_t kernel_size;                  /* ConvNet trunk: 1 or 3; others: 3.  With hex: the hexagdly size, 1 */
+  int32_t hex;                          /* 1: every conv is hexagdly.Conv2d(kernel_size=1): centre + 6 neighbours on a
+                                           grid whose odd columns sit half a cell lower; each conv then has TWO weight
+                                           tensors, kernel0 [out][in][3][1] and kernel1 [out][in][2][2].  nz_boardnet_*
+                                           only; restated from the hexagdly documentation, parity unpinned (the package
+                                           is not installed here).  nz_engine_set_weights rejects it. */
 } nz_net_desc;
 
 /* Fixed per-engine sizes, for sizing the caller's export buffers. */

@@ -39,7 +39,7 @@ class GameDesc(Structure):
 class NetDesc(Structure):
     _fields_ = [("in_channels", c_int32), ("policy_channels", c_int32), ("width", c_int32),
                 ("num_blocks", c_int32), ("recall", c_int32), ("value_activation", c_int32),
-                ("arch", c_int32), ("kernel_size", c_int32)]
+                ("arch", c_int32), ("kernel_size", c_int32), ("hex", c_int32)]
 
 
 class Dims(Structure):

@@ -20,7 +20,7 @@ _ARCH = {"recurrent": _lib.NZ_ARCH_RECURRENT, "resnet": _lib.NZ_ARCH_RESNET, "co
 
 class BoardNet:
     def __init__(self, arch, in_channels, policy_channels, rows, cols, width=64, num_blocks=2, recall=True,
-                 value_activation="tanh", kernel_size=3, max_batch=1024, device=0):
+                 value_activation="tanh", kernel_size=3, max_batch=1024, device=0, hex=False):
         if not torch.cuda.is_available():
             raise RuntimeError("nuzero_amd needs a ROCm GPU; there is no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -30,7 +30,7 @@ class BoardNet:
         self.max_batch = int(max_batch)
         self.desc = _lib.NetDesc(in_channels, policy_channels, width, num_blocks, int(bool(recall)),
                                  _lib.NZ_ACT_RELU if value_activation == "relu" else _lib.NZ_ACT_TANH,
-                                 _ARCH[arch], kernel_size)
+                                 _ARCH[arch], 1 if hex else kernel_size, int(bool(hex)))
         self._h = c_void_p(0)
         st = lib.nz_boardnet_create(byref(self._h), byref(self.desc), self.rows, self.cols, self.max_batch, device)
         if st != _lib.NZ_OK:

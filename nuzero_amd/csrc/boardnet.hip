@@ -45,7 +45,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgs {
   const float* src0;     // [rows][c0] NHWC, c0 a multiple of 16
   const float* src1;     // second K source (recall concat) or nullptr
-  const float* w;        // packed [ntile][10 taps][kg0 + kg1][64 lanes][4]
+  const float* w;        // packed [ntile][taps + 1][kg0 + kg1][64 lanes][4]
   const float* res;      // residual [rows][cd] or nullptr
   float* dst;            // [rows][cd]
   const int32_t* n_dev;  // live positions on the device (nullptr: n_host)
@@ -53,6 +53,7 @@ struct ConvArgs {
   int32_t c0, c1;        // K extent of each source in channels (multiples of 16)
   int32_t s0, s1, cd;    // channel strides of the sources and of dst
   int32_t act;           // 0 none, 1 relu, 2 tanh, 3 elu
+  int32_t hex;           // 0: 3x3 square taps; 1: 7 hexagonal taps (centre + 6 neighbours, odd columns shifted down)
 };
 
 __device__ __forceinline__ float activate(float v, int act) {
@@ -65,7 +66,7 @@ __device__ __forceinline__ float activate(float v, int act) {
 }
 
 // K steps in flight per wavefront: the loads of step i + DEPTH are issued before the MFMAs of step i.
-template <int MT, int NT, int DEPTH>
+template <int MT, int NT, int DEPTH, bool HEX>
 __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -78,14 +79,18 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   const int nt0 = blockIdx.y * NT;
   const int kg0 = p.c0 >> 4, kg1 = p.src1 ? (p.c1 >> 4) : 0, kgt = kg0 + kg1;
 
+  // Taps.  Square: tap = 3 (dy + 1) + (dx + 1).  Hexagonal (hexagdly's addressing: odd columns sit half a cell
+  // lower): 0 N, 1 centre, 2 S (same column), 3 NW, 4 SW (column - 1), 5 NE, 6 SE (column + 1); the upper / lower
+  // neighbour in an adjacent column is row - 1 / row for a cell in an even column, row / row + 1 in an odd one.
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int cy = cell / p.wd, cx = cell % p.wd;
+  auto tap_dy = [&](int tap) { return HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1; };
+  auto tap_dx = [&](int tap) { return HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1; };
   uint32_t vmask = 0;                                // taps that stay on the board for this cell
-  {
-    const int cy = cell / p.wd, cx = cell % p.wd;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int y = cy + tap / 3 - 1, x = cx + tap % 3 - 1;
-      if ((unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.wd) vmask |= 1u << tap;
-    }
+  for (int tap = 0; tap < 9; ++tap) {
+    const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
+    if (tap < ntaps && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.wd) vmask |= 1u << tap;
   }
   int row[MT];
   bool live[MT];
@@ -101,9 +106,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // packed weights: [column tile][10 taps][kgt][64 lanes][4]; "tap 9" is a block of zeros that the
+  // packed weights: [column tile][ntaps + 1][kgt][64 lanes][4]; "tap ntaps" is a block of zeros that the
   // steps past the end of the K loop read, so the pipeline needs no conditional loads
-  const size_t tile_stride = (size_t)10 * kgt * 256;
+  const size_t tile_stride = (size_t)(ntaps + 1) * kgt * 256;
   const float* wbase = p.w + (size_t)nt0 * tile_stride + lane * 4;
   const int q4 = (lane >> 4) * 4;
 
@@ -125,12 +130,12 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
       if (++kg == kgt) {
         kg = 0;
         if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
-        else tap = 9;
+        else tap = ntaps;
       }
       return;
     }
 #endif
-    const int shift = ((tap / 3 - 1) * p.wd + (tap % 3 - 1)) * 16;
+    const int shift = (tap_dy(tap) * p.wd + tap_dx(tap)) * 16;
     const bool second = kg >= kg0;
     const float* src = second ? p.src1 : p.src0;
     const int cs = second ? p.s1 : p.s0;
@@ -138,9 +143,9 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #ifdef NZ_ABLATE_CONV_A            // timing experiment: every activation load hits the same rows
-      if (live[m] && tap < 9) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)row[m] * cs + q4);
+      if (live[m] && tap < ntaps) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)row[m] * cs + q4);
 #else
-      if (live[m] && tap < 9) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)(row[m] + shift) * cs + ch);
+      if (live[m] && tap < ntaps) a[d][m] = *reinterpret_cast<const f32x4*>(src + (size_t)(row[m] + shift) * cs + ch);
 #endif
       else a[d][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
     if (++kg == kgt) {
       kg = 0;
       if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
-      else tap = 9;
+      else tap = ntaps;
     }
   };
   auto mac = [&](int d) {
@@ -304,17 +309,30 @@ std::vector<int> head_channels(int width, int out, int layers) {   // blocks.py:
 }
 
 // weights [cout][c0 + c1][k][k] (k = 1 or 3) -> the per-lane stream conv_kernel reads.
-bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c0p, int c1p) {
+// weights -> the per-lane stream conv_kernel reads.  Square: w0 = [cout][c0 + c1][k][k] (k = 1 or 3), w1 unused.
+// Hexagonal (hexagdly.Conv2d, kernel_size 1): w0 = kernel0 [cout][cin][3][1] (the cell's own column: N, centre, S),
+// w1 = kernel1 [cout][cin][2][2] ([upper, lower] x [left column, right column]).
+bool pack(nz_boardnet* h, const float* w0, const float* w1, int cout, int c0, int c1, int k, int c0p, int c1p) {
+  const bool hex = h->net.hex != 0;
+  const int ntaps = hex ? 7 : 9;
   PackedConv pc;
   pc.cout = cout; pc.coutp = pad16(cout); pc.cin = c0 + c1; pc.c0p = c0p; pc.c1p = c1p;
-  const int ntiles = pc.coutp / 16, kgt = (c0p + c1p) / 16;
-  std::vector<float> host((size_t)ntiles * 10 * kgt * 256, 0.f);      // tap 9: zeros (see conv_kernel)
-  std::vector<float> wh((size_t)cout * (c0 + c1) * k * k);
-  if (hipMemcpy(wh.data(), w, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return false;
+  const int ntiles = pc.coutp / 16, kgt = (c0p + c1p) / 16, cin = c0 + c1;
+  std::vector<float> host((size_t)ntiles * (ntaps + 1) * kgt * 256, 0.f);      // last tap: zeros (see conv_kernel)
+  std::vector<float> wh((size_t)cout * cin * (hex ? 3 : k * k)), wh1(hex ? (size_t)cout * cin * 4 : 0);
+  if (hipMemcpy(wh.data(), w0, wh.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return false;
+  if (hex && hipMemcpy(wh1.data(), w1, wh1.size() * sizeof(float), hipMemcpyDefault) != hipSuccess) return false;
+  auto weight = [&](int co, int ci, int tap) -> float {
+    if (hex) {
+      if (tap < 3) return wh[((size_t)co * cin + ci) * 3 + tap];
+      const int side = tap >= 5, lower = (tap - 3) & 1;                      // 3 NW, 4 SW, 5 NE, 6 SE
+      return wh1[(((size_t)co * cin + ci) * 2 + lower) * 2 + side];
+    }
+    if (k == 1) return tap == 4 ? wh[(size_t)co * cin + ci] : 0.f;
+    return wh[((size_t)co * cin + ci) * 9 + tap];
+  };
   for (int nt = 0; nt < ntiles; ++nt)
-    for (int tap = 0; tap < 9; ++tap) {
-      if (k == 1 && tap != 4) continue;
-      const int wt = k == 1 ? 0 : tap;
+    for (int tap = 0; tap < ntaps; ++tap)
       for (int kg = 0; kg < kgt; ++kg)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 4; ++j) {
@@ -324,16 +342,25 @@ bool pack(nz_boardnet* h, const float* w, int cout, int c0, int c1, int k, int c
             if (ch < c0p) cin_idx = ch < c0 ? ch : -1;
             else { ch -= c0p; cin_idx = ch < c1 ? c0 + ch : -1; }
             if (co >= cout || cin_idx < 0) continue;
-            host[(((size_t)nt * 10 + tap) * kgt + kg) * 256 + lane * 4 + j] =
-                wh[((size_t)co * (c0 + c1) + cin_idx) * k * k + wt];
+            host[(((size_t)nt * (ntaps + 1) + tap) * kgt + kg) * 256 + lane * 4 + j] = weight(co, cin_idx, tap);
           }
-    }
   if (hipMalloc((void**)&pc.dev, host.size() * sizeof(float)) != hipSuccess) return false;
   if (hipMemcpy(pc.dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
   h->convs.push_back(pc);
   // algorithmic flops per position: taps inside the board only
-  const int64_t taps = k == 1 ? (int64_t)h->hw : (int64_t)(3 * h->rows - 2) * (3 * h->cols - 2);
-  h->flops += 2 * taps * (c0 + c1) * cout;
+  int64_t taps = 0;
+  if (hex) {
+    for (int r = 0; r < h->rows; ++r)
+      for (int c = 0; c < h->cols; ++c) {
+        const int up = (c & 1) ? r : r - 1, lo = up + 1;
+        taps += 1 + (r > 0) + (r + 1 < h->rows);
+        for (int dc = -1; dc <= 1; dc += 2)
+          if (c + dc >= 0 && c + dc < h->cols) taps += (up >= 0 && up < h->rows) + (lo >= 0 && lo < h->rows);
+      }
+  } else {
+    taps = k == 1 ? (int64_t)h->hw : (int64_t)(3 * h->rows - 2) * (3 * h->cols - 2);
+  }
+  h->flops += 2 * taps * cin * cout;
   return true;
 }
 
@@ -342,7 +369,8 @@ void launch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
   const int groups = (a.n_host + 15) / 16;
   const int tasks = (groups + MT - 1) / MT * a.hw;           // wavefronts: one board cell of MT position groups
   dim3 grid((tasks + 3) / 4, ntiles / NT);
-  hipLaunchKernelGGL((conv_kernel<MT, NT, DEPTH>), grid, dim3(256), 0, s, a);
+  if (a.hex) hipLaunchKernelGGL((conv_kernel<MT, NT, DEPTH, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_kernel<MT, NT, DEPTH, false>), grid, dim3(256), 0, s, a);
 }
 
 // Tile shape per layer: NT = as many 16-column tiles as divide the layer's width (up to 4), so
@@ -395,6 +423,8 @@ nz_status nz_boardnet_create(nz_boardnet** out, const nz_net_desc* net, int32_t 
     return bfail(nullptr, NZ_ERR_ARG, "unknown architecture %d", net->arch);
   if (net->arch == NZ_ARCH_CONVNET && net->kernel_size != 1 && net->kernel_size != 3)
     return bfail(nullptr, NZ_ERR_ARG, "ConvNet kernel_size must be 1 or 3");
+  if (net->hex && net->arch == NZ_ARCH_CONVNET && net->kernel_size != 1)
+    return bfail(nullptr, NZ_ERR_ARG, "hexagonal ConvNet: only kernel_size 1 (centre + 6 neighbours) is built");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
     return bfail(nullptr, NZ_ERR_HIP, "no HIP device %d (no CPU fallback)", device);
@@ -433,10 +463,12 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
   const int vact = nd.value_activation == NZ_ACT_RELU ? 1 : 2;
   int wi = 0;
+  const int per_conv = nd.hex ? 2 : 1;           // hexagdly.Conv2d holds kernel0 and kernel1
   auto add = [&](int cout, int c0, int c1, int k, int c0p, int c1p, int src0, int src1, int res, int dst, int act) {
-    if (!pack(h, weights[wi], cout, c0, c1, k, c0p, c1p)) return false;
+    if (wi + per_conv > n_weights) return false;
+    if (!pack(h, weights[wi], nd.hex ? weights[wi + 1] : nullptr, cout, c0, c1, k, c0p, c1p)) return false;
     h->ops.push_back(ConvOp{src0, src1, res, dst, wi, act});
-    ++wi;
+    wi += per_conv;
     return true;
   };
   bool ok = true;
@@ -449,7 +481,7 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   };
   if (nd.arch == NZ_ARCH_RECURRENT) {
     const int per_iter = (nd.recall ? 1 : 0) + 2 * nd.num_blocks;
-    if (n_weights != 1 + per_iter + 6) return bfail(h, NZ_ERR_ARG, "RecurrentNet needs %d tensors, got %d", 1 + per_iter + 6, n_weights);
+    if (n_weights != (1 + per_iter + 6) * per_conv) return bfail(h, NZ_ERR_ARG, "RecurrentNet needs %d tensors, got %d", (1 + per_iter + 6) * per_conv, n_weights);
     if (recurrent_iterations < 1) return bfail(h, NZ_ERR_ARG, "recurrent_iterations must be >= 1");
     ok = add(W, IN, 0, 3, INp, 0, 0, -1, -1, 1, 1);
     const int first = wi;
@@ -462,13 +494,13 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
       }
       for (int b = 0; b < nd.num_blocks && ok; ++b) block(wi);
     }
-    wi = first + per_iter;
+    wi = first + per_iter * per_conv;
   } else if (nd.arch == NZ_ARCH_RESNET) {
-    if (n_weights != 1 + 2 * nd.num_blocks + 6) return bfail(h, NZ_ERR_ARG, "ResNet needs %d tensors, got %d", 1 + 2 * nd.num_blocks + 6, n_weights);
+    if (n_weights != (1 + 2 * nd.num_blocks + 6) * per_conv) return bfail(h, NZ_ERR_ARG, "ResNet needs %d tensors, got %d", (1 + 2 * nd.num_blocks + 6) * per_conv, n_weights);
     ok = add(W, IN, 0, 3, INp, 0, 0, -1, -1, 1, 1);
     for (int b = 0; b < nd.num_blocks && ok; ++b) block(wi);
   } else {
-    if (n_weights != 1 + nd.num_blocks + 6) return bfail(h, NZ_ERR_ARG, "ConvNet needs %d tensors, got %d", 1 + nd.num_blocks + 6, n_weights);
+    if (n_weights != (1 + nd.num_blocks + 6) * per_conv) return bfail(h, NZ_ERR_ARG, "ConvNet needs %d tensors, got %d", (1 + nd.num_blocks + 6) * per_conv, n_weights);
     const int k = nd.kernel_size;
     ok = add(W, IN, 0, k, INp, 0, 0, -1, -1, 1, 3);
     for (int i = 0; i < nd.num_blocks && ok; ++i) {
@@ -534,6 +566,7 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
     a.s1 = op.src1 >= 0 ? h->buffer_channels[op.src1] : 0;
     a.cd = h->buffer_channels[op.dst];
     a.act = op.act;
+    a.hex = h->net.hex ? 1 : 0;
     if (a.c0 > a.s0 || a.c1 > a.s1 || pc.coutp > a.cd) return bfail(h, NZ_ERR_STATE, "internal: layer shapes disagree");
     dispatch_conv(a, pc.coutp / 16, s);
   }

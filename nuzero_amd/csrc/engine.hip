@@ -417,6 +417,7 @@ nz_status nz_engine_dims(const nz_engine* e, nz_dims* out) {
 nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const float* const* weights,
                                 int32_t n_tensors, int32_t recurrent_iterations) {
   if (!e || !net || !weights) return NZ_ERR_ARG;
+  if (net->hex) return fail(e, NZ_ERR_ARG, "hexagonal convolutions are built for nz_boardnet_* only");
   if (net->in_channels != 2 || net->policy_channels != 1)
     return fail(e, NZ_ERR_ARG, "Tic-Tac-Toe nets take 2 input planes and 1 policy plane");
   if (net->width <= 0 || net->width > 64 || net->width % 4 != 0)

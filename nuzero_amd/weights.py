@@ -97,3 +97,14 @@ def synthetic_recurrent_net_weights(seed, in_channels, policy_channels, width=64
         bound = gain / math.sqrt(fan_in)
         out[name] = rs.uniform(-bound, bound, size=shape).astype(np.float32)
     return out
+
+
+def hex_param_shapes(shapes):
+    """The same network with hex=True: every conv is hexagdly.Conv2d(kernel_size=1), whose parameters are
+    kernel0 [out, in, 3, 1] (the cell's own column) and kernel1 [out, in, 2, 2] (the two adjacent columns)."""
+    out = []
+    for name, (o, i, _kh, _kw) in shapes:
+        base = name[:-len("weight")]
+        out.append((base + "kernel0", (o, i, 3, 1)))
+        out.append((base + "kernel1", (o, i, 2, 2)))
+    return out

@@ -149,3 +149,82 @@ class FeedForwardRef:
         finally:
             torch.set_num_threads(n)
         return p.numpy(), v.numpy()
+
+
+# ---- hexagonal convolutions: PARITY UNPINNED ------------------------------------------------------------
+# hexagdly is not installed in the build container, so nothing below could be checked against it or against
+# outputs of the reference's hex=True nets.  It restates hexagdly.Conv2d(kernel_size=1, bias=False) from the
+# package's documentation: a 7-cell neighbourhood on a grid whose odd columns sit half a cell lower -- the
+# adjacency SCS_Game uses (Games/SCS/SCS_Game.py:1199-1243; tests/test_hex_oracle.py checks that much) --
+# with kernel0 [out, in, 3, 1] = (N, centre, S) of the cell's own column and kernel1 [out, in, 2, 2] =
+# [upper, lower] x [left column, right column].
+def hex_conv2d(x, kernel0, kernel1):
+    x = torch.as_tensor(x, dtype=torch.float32)
+    k0 = torch.as_tensor(np.asarray(kernel0), dtype=torch.float32)
+    k1 = torch.as_tensor(np.asarray(kernel1), dtype=torch.float32)
+    n, _, rows, cols = x.shape
+    out = F.conv2d(x, k0, None, 1, (1, 0))                           # own column: rows r-1, r, r+1
+    xp = F.pad(x, (1, 1, 1, 1))                                      # zero border: xp[r + 1, c + 1] = x[r, c]
+    even = (torch.arange(cols) % 2 == 0).reshape(1, 1, 1, cols)
+
+    def shifted(dr, dc):                                             # t[r, c] = x[r + dr, c + dc] (0 outside)
+        return xp[:, :, 1 + dr:1 + dr + rows, 1 + dc:1 + dc + cols]
+
+    for side, dc in ((0, -1), (1, 1)):
+        upper = torch.where(even, shifted(-1, dc), shifted(0, dc))   # even column: rows r-1 / r; odd: r / r+1
+        lower = torch.where(even, shifted(0, dc), shifted(1, dc))
+        out = out + F.conv2d(upper, k1[:, :, 0:1, side:side + 1]) + F.conv2d(lower, k1[:, :, 1:2, side:side + 1])
+    return out
+
+
+class HexNetRef:
+    """RecurrentNet / ResNet / ConvNet with hex=True (every conv a hexagdly.Conv2d(kernel_size=1)); weights keyed
+    `<layer>.kernel0` / `<layer>.kernel1` in state_dict order.  Parity unpinned (see above)."""
+
+    def __init__(self, weights, arch, num_blocks, recall=True, value_activation="tanh"):
+        self.w = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32) for k, v in weights.items()}
+        self.arch, self.num_blocks, self.recall, self.value_activation = arch, num_blocks, recall, value_activation
+        self.recurrent = arch == "recurrent"
+
+    def _conv(self, x, layer):
+        return hex_conv2d(x, self.w[layer + ".kernel0"], self.w[layer + ".kernel1"])
+
+    def forward(self, x, iters=1):
+        x = torch.as_tensor(x, dtype=torch.float32)
+        c = self._conv
+        if self.arch == "recurrent":
+            t = F.relu(c(x, "projection.0"))
+            base = 1 if self.recall else 0
+            for _ in range(iters):
+                if self.recall:
+                    t = c(torch.cat([t, x], 1), "recur_module.0")
+                for b in range(self.num_blocks):
+                    pre = f"recur_module.{base + b}.before_shortcut."
+                    t = F.relu(c(F.relu(c(t, pre + "0")), pre + "2") + t)
+        elif self.arch == "resnet":
+            t = F.relu(c(x, "input_block.0"))
+            for b in range(self.num_blocks):
+                pre = f"residual_blocks.{b}.before_shortcut."
+                t = F.relu(c(F.relu(c(t, pre + "0")), pre + "2") + t)
+        else:
+            t = F.elu(c(x, "general_module.0"))
+            for i in range(self.num_blocks):
+                t = F.elu(c(t, f"general_module.{2 * (i + 1)}"))
+        p = c(F.relu(c(t, "policy_head.layers.0")), "policy_head.layers.2")
+        act = torch.tanh if self.value_activation == "tanh" else F.relu
+        v = t
+        for i in range(4):
+            v = c(v, f"value_head.layers.{2 * i}")
+            if i != 3:
+                v = act(v)
+        return p, torch.tanh(v.mean(dim=(1, 2, 3)).reshape(-1, 1))
+
+    def inference(self, state, iters=1):
+        n = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            with torch.no_grad():
+                p, v = self.forward(state, iters or 1)
+        finally:
+            torch.set_num_threads(n)
+        return p.numpy(), v.numpy()

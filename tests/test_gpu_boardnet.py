@@ -173,3 +173,37 @@ def test_native_move_loop_plays_the_same_games_as_the_lockstep_api():
     assert ra["expansions"] == rb["expansions"] and ra["simulations"] == rb["simulations"]
     assert rb["waves"] > 0
     a.close(); b.close(); net.close()
+
+
+@pytest.mark.parametrize("arch,cin,planes,rows,cols,width,depth,recall,vact,iters,n", [
+    ("recurrent", 86, 21, 5, 5, 32, 2, True, "relu", 2, 37),
+    ("resnet", 105, 30, 6, 5, 48, 2, False, "tanh", 1, 50),
+    ("convnet", 86, 21, 10, 10, 32, 3, False, "tanh", 1, 19)])
+def test_hexagonal_nets_equal_the_oracle(arch, cin, planes, rows, cols, width, depth, recall, vact, iters, n):
+    """hex=True nets (every conv a hexagdly.Conv2d(kernel_size=1): two weight tensors per conv, 7 taps with
+    column-parity offsets) against oracle/net.py HexNetRef.  PARITY UNPINNED: hexagdly is not installed, the
+    oracle restates its documented addressing (tests/test_hex_oracle.py ties it to the game's adjacency)."""
+    import torch
+    from scipy.special import softmax
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.weights import (synthetic_weights, hex_param_shapes, recurrent_net_param_shapes, resnet_param_shapes,
+                                    convnet_param_shapes)
+    from oracle.net import HexNetRef
+    if arch == "recurrent":
+        shapes = recurrent_net_param_shapes(cin, planes, width, depth, recall)
+    elif arch == "resnet":
+        shapes = resnet_param_shapes(cin, planes, width, depth)
+    else:
+        shapes = convnet_param_shapes(cin, planes, 3, width, depth)
+    w = synthetic_weights(21, hex_param_shapes(shapes), 2.0)
+    rs = np.random.RandomState(5)
+    x = (rs.random_sample((n, cin, rows, cols)) < 0.15).astype(np.float32)
+    x[:, -3:] = rs.random_sample((n, 3, rows, cols)).astype(np.float32)
+    net = BoardNet(arch, cin, planes, rows, cols, width=width, num_blocks=depth, recall=recall, value_activation=vact,
+                   max_batch=n, hex=True)
+    net.set_weights(w, iters)
+    probs, value, logits = net.forward(torch.from_numpy(x).cuda(), want_logits=True)
+    p, v = HexNetRef(w, arch, depth, recall, vact).inference(x, iters)
+    p = p.reshape(n, -1)
+    _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(), softmax(p, axis=1), v.reshape(-1), p)
+    net.close()
