@@ -68,6 +68,9 @@ def main():
                     help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
     ap.add_argument("--nodes-per-sim", type=int, default=2048,
                     help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="split the concurrent games into this many independent sets, each with its own engine, network "
+                         "buffers, host thread and HIP stream (native evaluator, library loop): their small kernels overlap")
     ap.add_argument("--cpu-seconds", type=float, default=0.0, help="also time the CPU oracle for this long")
     ap.add_argument("--config", default=os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
     args = ap.parse_args()
@@ -142,7 +145,36 @@ def main():
     if world > 1:
         td.barrier()
     t0 = time.perf_counter()
-    if args.evaluator == "native" and args.loop == "library":
+    if args.evaluator == "native" and args.loop == "library" and args.streams > 1:
+        import threading
+        S = args.streams
+        assert args.games % S == 0
+        per = args.games // S
+        sets = []
+        for i in range(S):
+            n_i = BoardNet(args.arch, cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
+                           num_blocks=args.layers, kernel_size=3, max_batch=per, device=local, hex=args.hex)
+            n_i.set_weights(w, args.iters)
+            sets.append((ScsSelfPlay(cfg, search, per, nodes_per_game=1 + args.sims * args.nodes_per_sim, device=local), n_i,
+                         torch.cuda.Stream(device=local)))
+        results = [None] * S
+
+        def run(i):
+            sp_i, n_i, st = sets[i]
+            with torch.cuda.stream(st):
+                results[i] = sp_i.play_native(n_i, seeds[i * per:(i + 1) * per])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(S)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert all(x is not None for x in results), "a stream's games failed"
+        r = {k: np.concatenate([x[k] for x in results], 0) for k in results[0] if isinstance(results[0][k], np.ndarray)}
+        for k in ("simulations", "expansions", "waves"):
+            r[k] = sum(x[k] for x in results)
+    elif args.evaluator == "native" and args.loop == "library":
         r = sp.play_native(net, seeds)
     else:
         r = sp.play(ev, seeds=seeds)
@@ -176,7 +208,7 @@ def main():
                                                     args.evaluator, args.loop if native else "python"),
                       "net_flops_per_position": net.flops_per_position if native else None,
                       "net_tflops": n_exp * net.flops_per_position / dt / 1e12 if native else None,
-                      "waves": r.get("waves"), "n_gpus": world, "scaling": "weak",
+                      "waves": r.get("waves"), "n_gpus": world, "scaling": "weak", "streams": args.streams,
                       "games_per_s": n_games / dt, "expansions_per_s": n_exp / dt,
                       "simulations_per_s": n_sim / dt, "seconds": dt,
                       "mean_game_length": float(r["lengths"].mean()),
