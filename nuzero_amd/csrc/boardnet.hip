@@ -46,6 +46,8 @@ struct ConvArgs {
   const float* src0;     // [rows][c0] NHWC, c0 a multiple of 16
   const float* src1;     // second K source (recall concat) or nullptr
   const float* w;        // packed [ntile][taps + 1][kg0 + kg1][64 lanes][4]
+  const uint32_t* ws;    // wide layers: weights as three bf16 pieces, [cout tile of 128][taps + 1][32-channel group]
+                         // [piece][column tile 8][64 lanes][8 bf16], or nullptr
   const float* res;      // residual [rows][cd] or nullptr
   float* dst;            // [rows][cd]
   const int32_t* n_dev;  // live positions on the device (nullptr: n_host)
@@ -199,6 +201,196 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
   }
 }
 
+// ---- wide layers (output channels a multiple of 128) on the BF16 matrix cores ----------------------
+// Same arithmetic as the fused 3x3 network (net_dev.hpp): every float32 product from six bf16 MFMA terms
+// on exact three-way splits, float32 accumulation -- 96 cycles per 32 channels instead of 256.  At that
+// rate the operands cannot come straight from L2 any more, so a workgroup (4 wavefronts) computes a
+// 256-position x 128-channel tile of ONE board cell: per K step (tap, 32 input channels) it stages the
+// 256 x 32 activations (read as float32, split once, 3 x 16 KB of bf16) and the 128 x 32 weights (already
+// split on the host, 24 KB) in LDS, double buffered, one barrier per step; each wavefront owns 128
+// positions x 64 channels = 32 accumulator tiles and issues 192 MFMAs per step from 36 LDS fragment reads.
+// Weights are the MFMA's A operand, so a lane ends up with four consecutive channels of one position:
+// the epilogue is one 16-byte store (and residual load) per accumulator tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int WIDE_GROUPS = 16;          // position groups (of 16) per workgroup tile
+constexpr int WIDE_NT = 8;               // 16-channel column tiles per workgroup tile
+
+__device__ __forceinline__ uint32_t wide_pack_hi16(float x0, float x1) {
+  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, x0), 0x07060302u);
+}
+__device__ __forceinline__ float wide_trunc(float x) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
+}
+// 8 float32 -> three bf16 pieces (exact: 8 + 8 + 8 significant bits)
+__device__ __forceinline__ void wide_split8(const f32x4& lo, const f32x4& hi, u32x4& p0, u32x4& p1, u32x4& p2) {
+  const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  uint32_t a[4], b[4], c[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float x0 = v[2 * j], x1 = v[2 * j + 1];
+    a[j] = wide_pack_hi16(x0, x1);
+    const float r0 = x0 - wide_trunc(x0), r1 = x1 - wide_trunc(x1);
+    b[j] = wide_pack_hi16(r0, r1);
+    c[j] = wide_pack_hi16(r0 - wide_trunc(r0), r1 - wide_trunc(r1));
+  }
+  p0 = u32x4{a[0], a[1], a[2], a[3]};
+  p1 = u32x4{b[0], b[1], b[2], b[3]};
+  p2 = u32x4{c[0], c[1], c[2], c[3]};
+}
+__device__ __forceinline__ f32x4 wide_mfma(const u32x4& w, const u32x4& x, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+
+template <bool HEX>
+__global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
+  __shared__ u32x4 sA[2][3][WIDE_GROUPS * 16][4];      // [buffer][piece][position][16-byte slot, swizzled]
+  __shared__ u32x4 sB[2][3][WIDE_NT][64];              // [buffer][piece][column tile][lane]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_pos = p.n_dev ? *p.n_dev : p.n_host;
+  const int n_groups = (n_pos + 15) >> 4;
+  const int cell = blockIdx.x % p.hw, gbase = (blockIdx.x / p.hw) * WIDE_GROUPS;
+  if (gbase >= n_groups) return;                       // uniform per workgroup
+  const int ct = blockIdx.y;                           // tile of 128 output channels
+  const int kq0 = p.c0 >> 5, kq1 = p.src1 ? (p.c1 >> 5) : 0, kqt = kq0 + kq1;      // 32-channel groups
+
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int cy = cell / p.wd, cx = cell % p.wd;
+  auto tap_dy = [&](int tap) { return HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1; };
+  auto tap_dx = [&](int tap) { return HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1; };
+  uint32_t vmask = 0;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
+    if (tap < ntaps && (unsigned)y < (unsigned)p.h && (unsigned)x < (unsigned)p.wd) vmask |= 1u << tap;
+  }
+  const int total = __popc(vmask) * kqt;
+
+  // staging roles: 8 lanes cover the 128 bytes (32 channels) of one row, so a load instruction touches 8 full cache
+  // lines; thread t fetches 16 bytes (4 channels) of positions (t >> 3) + 32 j, j = 0..7, and 6 x 16 bytes of weights
+  const int my_chunk = tid & 7;
+  int my_row[8];
+  bool my_live[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ppos = (tid >> 3) + 32 * j, group = gbase + (ppos >> 4);
+    my_live[j] = group < n_groups;
+    my_row[j] = (group * p.hw + cell) * 16 + (ppos & 15);
+  }
+  const u32x4* wtile = reinterpret_cast<const u32x4*>(p.ws) + (size_t)ct * (ntaps + 1) * kqt * (3 * WIDE_NT * 64);
+  uint32_t taps_left = vmask;
+  int tap = __ffs(taps_left) - 1, kq = 0;              // the centre tap is always on the board
+  taps_left &= taps_left - 1;
+  f32x4 ra[8];
+  u32x4 rb[6];
+  auto fetch = [&]() {                                 // global -> registers for the cursor's step, then advance
+    const int shift = (tap_dy(tap) * p.wd + tap_dx(tap)) * 16;
+    const bool second = kq >= kq0;
+    const float* src = (second ? p.src1 : p.src0) + (second ? kq - kq0 : kq) * 32 + my_chunk * 4;
+    const int cs = second ? p.s1 : p.s0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      ra[j] = my_live[j] ? *reinterpret_cast<const f32x4*>(src + (size_t)(my_row[j] + shift) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const u32x4* wsrc = wtile + ((size_t)tap * kqt + kq) * (3 * WIDE_NT * 64);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) rb[j] = wsrc[tid + j * 256];
+    if (++kq == kqt) {
+      kq = 0;
+      if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
+      else tap = ntaps;
+    }
+  };
+  // registers -> LDS
+  auto stage_a = [&](int buf, int j) {                 // row slice j: 4 channels -> 8 bytes per piece (activations split here, once)
+    unsigned char* ab = reinterpret_cast<unsigned char*>(&sA[buf][0][0][0]);
+    const int ppos = (tid >> 3) + 32 * j;
+    const int off = ppos * 64 + (((my_chunk >> 1) ^ ((ppos >> 2) & 3)) << 4) + (my_chunk & 1) * 8;
+    const float x0 = ra[j][0], x1 = ra[j][1], x2 = ra[j][2], x3 = ra[j][3];
+    const float r0 = x0 - wide_trunc(x0), r1 = x1 - wide_trunc(x1), r2 = x2 - wide_trunc(x2), r3 = x3 - wide_trunc(x3);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<u32x2*>(ab + 0 * (WIDE_GROUPS * 16 * 64) + off) = u32x2{wide_pack_hi16(x0, x1), wide_pack_hi16(x2, x3)};
+    *reinterpret_cast<u32x2*>(ab + 1 * (WIDE_GROUPS * 16 * 64) + off) = u32x2{wide_pack_hi16(r0, r1), wide_pack_hi16(r2, r3)};
+    *reinterpret_cast<u32x2*>(ab + 2 * (WIDE_GROUPS * 16 * 64) + off) =
+        u32x2{wide_pack_hi16(r0 - wide_trunc(r0), r1 - wide_trunc(r1)), wide_pack_hi16(r2 - wide_trunc(r2), r3 - wide_trunc(r3))};
+  };
+  auto stage_b = [&](int buf) {
+    u32x4* fb = &sB[buf][0][0][0];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fb[tid + j * 256] = rb[j];
+  };
+
+  // compute roles: wavefront = (half of the positions, half of the channels)
+  const int ph = wave & 1, ch = wave >> 1;
+  const int pos = lane & 15, quad = lane >> 4;
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  fetch();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) stage_a(0, j);
+  stage_b(0);
+  __syncthreads();
+  for (int s = 0; s < total; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < total;
+    if (more) fetch();                                 // the next step's operands fly under this step's MFMAs
+    u32x4 wf[4][3];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) wf[n][piece] = sB[buf][piece][ch * 4 + n][lane];
+    u32x4 xf[2][3];
+    auto load_x = [&](int g, int slot_buf) {
+      const int prow = (ph * 8 + g) * 16 + pos;
+      const int slot = quad ^ ((prow >> 2) & 3);
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) xf[slot_buf][piece] = sA[buf][piece][prow][slot];
+    };
+    load_x(0, 0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g + 1 < 8) load_x(g + 1, (g + 1) & 1);             // the next group's fragments fly under this group's MFMAs
+      const u32x4 x0 = xf[g & 1][0], x1 = xf[g & 1][1], x2 = xf[g & 1][2];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        acc[g][n] = wide_mfma(wf[n][1], x1, acc[g][n]);       // small terms first; one dependent chain
+        acc[g][n] = wide_mfma(wf[n][0], x2, acc[g][n]);
+        acc[g][n] = wide_mfma(wf[n][2], x0, acc[g][n]);
+        acc[g][n] = wide_mfma(wf[n][0], x1, acc[g][n]);
+        acc[g][n] = wide_mfma(wf[n][1], x0, acc[g][n]);
+        acc[g][n] = wide_mfma(wf[n][0], x0, acc[g][n]);
+        __builtin_amdgcn_sched_barrier(0);                     // keep the chain together (net_dev.hpp)
+      }
+    }
+    if (more) {                                                // staging after the MFMAs: slices between the chains were slower
+#pragma unroll
+      for (int j = 0; j < 8; ++j) stage_a(buf ^ 1, j);
+      stage_b(buf ^ 1);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    const int group = gbase + ph * 8 + g;
+    if (group >= n_groups) continue;
+    const size_t orow = (size_t)(group * p.hw + cell) * 16 + pos;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const size_t o = orow * p.cd + ct * 128 + (ch * 4 + n) * 16 + quad * 4;
+      f32x4 v = acc[g][n];
+      if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = activate(v[r], p.act);
+      *reinterpret_cast<f32x4*>(p.dst + o) = v;
+    }
+  }
+}
+
 __device__ __forceinline__ size_t row_of(size_t n, int cell, int hw) { return ((n >> 4) * hw + cell) * 16 + (n & 15); }
 
 // [n][C][H*W] (what Game.generate_network_input stacks) -> rows of cp channels, zero-padded in the
@@ -260,6 +452,7 @@ struct ConvOp {
 
 struct PackedConv {
   float* dev = nullptr;
+  uint32_t* dev_split = nullptr;            // wide layers only (conv_wide_kernel)
   int c0p = 0, c1p = 0, coutp = 0, cout = 0, cin = 0;
 };
 
@@ -346,6 +539,44 @@ bool pack(nz_boardnet* h, const float* w0, const float* w1, int cout, int c0, in
           }
   if (hipMalloc((void**)&pc.dev, host.size() * sizeof(float)) != hipSuccess) return false;
   if (hipMemcpy(pc.dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+  if (pc.coutp % 128 == 0 && c0p % 32 == 0 && c1p % 32 == 0) {      // wide layer: the split form for conv_wide_kernel
+    const int kqt = (c0p + c1p) / 32, cts = pc.coutp / 128;
+    std::vector<uint32_t> sp((size_t)cts * (ntaps + 1) * kqt * 3 * 8 * 64 * 4, 0u);
+    auto cin_of = [&](int ch) {                                       // channel within the padded concat -> tensor index
+      if (ch < c0p) return ch < c0 ? ch : -1;
+      ch -= c0p;
+      return ch < c1 ? c0 + ch : -1;
+    };
+    auto pieces = [](float a, uint16_t p3[3]) {                       // a = p3[0] + p3[1] + p3[2], bf16 each
+      float r = a;
+      for (int i = 0; i < 3; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &r, 4);
+        bits &= 0xFFFF0000u;
+        p3[i] = (uint16_t)(bits >> 16);
+        float t;
+        memcpy(&t, &bits, 4);
+        r = r - t;
+      }
+    };
+    for (int ct = 0; ct < cts; ++ct)
+      for (int tap = 0; tap < ntaps; ++tap)
+        for (int kq = 0; kq < kqt; ++kq)
+          for (int nt = 0; nt < 8; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int co = ct * 128 + nt * 16 + (lane & 15);
+                const int ci0 = cin_of(kq * 32 + (lane >> 4) * 8 + 2 * j), ci1 = cin_of(kq * 32 + (lane >> 4) * 8 + 2 * j + 1);
+                uint16_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                if (co < cout && ci0 >= 0) pieces(weight(co, ci0, tap), lo);
+                if (co < cout && ci1 >= 0) pieces(weight(co, ci1, tap), hi);
+                for (int piece = 0; piece < 3; ++piece)
+                  sp[((((((size_t)ct * (ntaps + 1) + tap) * kqt + kq) * 3 + piece) * 8 + nt) * 64 + lane) * 4 + j] =
+                      (uint32_t)lo[piece] | ((uint32_t)hi[piece] << 16);
+              }
+    if (hipMalloc((void**)&pc.dev_split, sp.size() * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMemcpy(pc.dev_split, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return false;
+  }
   h->convs.push_back(pc);
   // algorithmic flops per position: taps inside the board only
   int64_t taps = 0;
@@ -381,6 +612,17 @@ void launch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
 void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
   static const int force_mt = getenv("NZ_BOARDNET_MT") ? atoi(getenv("NZ_BOARDNET_MT")) : 0;   // tuning experiments
   const int kgt = (a.c0 + a.c1) / 16;
+  static const int force_wide = getenv("NZ_BOARDNET_WIDE") ? atoi(getenv("NZ_BOARDNET_WIDE")) : -1;     // tuning experiments
+  const int wide_tiles = ((a.n_host + 15) / 16 + WIDE_GROUPS - 1) / WIDE_GROUPS * a.hw * (ntiles / WIDE_NT);
+  // one workgroup per tile and per CU: below ~160 tiles the chip is too empty and the per-wavefront kernel wins
+  // (w256 5x5: 512 positions = 100 tiles 53 vs 59 TFLOP/s, 1024 = 200 tiles 96 vs 81; w128: 100 tiles 50 vs 58, 400 tiles 91 vs 81)
+  if (a.ws != nullptr && (force_wide < 0 ? wide_tiles >= 160 : force_wide != 0)) {
+    const int groups = (a.n_host + 15) / 16;
+    dim3 grid((groups + WIDE_GROUPS - 1) / WIDE_GROUPS * a.hw, ntiles / WIDE_NT);
+    if (a.hex) hipLaunchKernelGGL(conv_wide_kernel<true>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv_wide_kernel<false>, grid, dim3(256), 0, s, a);
+    return;
+  }
   if (ntiles % 4 == 0) {
     const int mt = force_mt ? force_mt : (a.n_host >= 1024 && kgt >= 8) ? 2 : 1;
     if (mt == 2) launch_conv<2, 4, 3>(a, ntiles, s);
@@ -408,7 +650,7 @@ void nz_boardnet_destroy(nz_boardnet* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (float* b : h->buffers) (void)hipFree(b);
-  for (auto& c : h->convs) (void)hipFree(c.dev);
+  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
   delete h;
 }
 
@@ -457,7 +699,7 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   if (!h || !weights) return NZ_ERR_ARG;
   B_HIP(h, hipSetDevice(h->device));
   B_HIP(h, hipDeviceSynchronize());
-  for (auto& c : h->convs) (void)hipFree(c.dev);
+  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
   h->convs.clear(); h->ops.clear(); h->flops = 0; h->ready = false;
   const nz_net_desc& nd = h->net;
   const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
@@ -558,6 +800,7 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
     a.src0 = h->buffers[op.src0];
     a.src1 = op.src1 >= 0 ? h->buffers[op.src1] : nullptr;
     a.w = pc.dev;
+    a.ws = pc.dev_split;
     a.res = op.res >= 0 ? h->buffers[op.res] : nullptr;
     a.dst = h->buffers[op.dst];
     a.n_dev = n_dev; a.n_host = n; a.hw = h->hw; a.h = h->rows; a.wd = h->cols;

@@ -207,3 +207,43 @@ def test_hexagonal_nets_equal_the_oracle(arch, cin, planes, rows, cols, width, d
     p = p.reshape(n, -1)
     _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(), softmax(p, axis=1), v.reshape(-1), p)
     net.close()
+
+
+@pytest.mark.parametrize("arch,cin,planes,rows,cols,width,depth,recall,vact,iters,n,hexnet", [
+    ("recurrent", 86, 21, 5, 5, 128, 1, True, "relu", 2, 1560, False),    # two K sources (recall), residuals
+    ("resnet", 86, 21, 5, 5, 256, 1, False, "tanh", 1, 790, False),       # two tiles of 128 channels, ragged tile of positions
+    ("convnet", 86, 21, 10, 10, 128, 2, False, "tanh", 1, 260, True)])    # hexagonal taps (unpinned)
+def test_wide_layers_equal_the_oracle(arch, cin, planes, rows, cols, width, depth, recall, vact, iters, n, hexnet):
+    """Layers whose width is a multiple of 128 run on conv_wide_kernel (float32 products from six bf16 MFMA terms,
+    LDS-staged 256-position x 128-channel tiles) when there are at least 160 such tiles -- the batch sizes here are
+    chosen so (ragged last tile included): same 1e-5 tolerance."""
+    import torch
+    from scipy.special import softmax
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.weights import (synthetic_weights, hex_param_shapes, recurrent_net_param_shapes, resnet_param_shapes,
+                                    convnet_param_shapes)
+    from oracle.net import FeedForwardRef, HexNetRef, RecurrentNetRef
+    if arch == "recurrent":
+        shapes = recurrent_net_param_shapes(cin, planes, width, depth, recall)
+    elif arch == "resnet":
+        shapes = resnet_param_shapes(cin, planes, width, depth)
+    else:
+        shapes = convnet_param_shapes(cin, planes, 3, width, depth)
+    w = synthetic_weights(31, hex_param_shapes(shapes) if hexnet else shapes, 2.0)
+    rs = np.random.RandomState(6)
+    x = (rs.random_sample((n, cin, rows, cols)) < 0.15).astype(np.float32)
+    x[:, -3:] = rs.random_sample((n, 3, rows, cols)).astype(np.float32)
+    net = BoardNet(arch, cin, planes, rows, cols, width=width, num_blocks=depth, recall=recall, value_activation=vact,
+                   max_batch=n, hex=hexnet)
+    net.set_weights(w, iters)
+    probs, value, logits = net.forward(torch.from_numpy(x).cuda(), want_logits=True)
+    if hexnet:
+        ref = HexNetRef(w, arch, depth, recall, vact)
+    elif arch == "recurrent":
+        ref = RecurrentNetRef(w, cin, planes, width, depth, recall, vact)
+    else:
+        ref = FeedForwardRef(w, arch, depth, vact)
+    p, v = ref.inference(x, iters)
+    p = p.reshape(n, -1)
+    _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(), softmax(p, axis=1), v.reshape(-1), p)
+    net.close()
