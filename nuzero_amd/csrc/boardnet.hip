@@ -291,7 +291,11 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     const int cs = second ? p.s1 : p.s0;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
+#ifdef NZ_ABLATE_WIDE_FETCH        // timing experiment: no activation loads (results wrong)
+      ra[j] = f32x4{(float)j, 1.f, 2.f, (float)shift};
+#else
       ra[j] = my_live[j] ? *reinterpret_cast<const f32x4*>(src + (size_t)(my_row[j] + shift) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
     const u32x4* wsrc = wtile + ((size_t)tap * kqt + kq) * (3 * WIDE_NT * 64);
 #pragma unroll
     for (int j = 0; j < 6; ++j) rb[j] = wsrc[tid + j * 256];
@@ -307,12 +311,20 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     const int ppos = (tid >> 3) + 32 * j;
     const int off = ppos * 64 + (((my_chunk >> 1) ^ ((ppos >> 2) & 3)) << 4) + (my_chunk & 1) * 8;
     const float x0 = ra[j][0], x1 = ra[j][1], x2 = ra[j][2], x3 = ra[j][3];
+#ifdef NZ_ABLATE_WIDE_SPLIT        // timing experiment: no split arithmetic (results wrong)
+    const float r0 = x1, r1 = x0, r2 = x3, r3 = x2;
+#else
     const float r0 = x0 - wide_trunc(x0), r1 = x1 - wide_trunc(x1), r2 = x2 - wide_trunc(x2), r3 = x3 - wide_trunc(x3);
+#endif
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     *reinterpret_cast<u32x2*>(ab + 0 * (WIDE_GROUPS * 16 * 64) + off) = u32x2{wide_pack_hi16(x0, x1), wide_pack_hi16(x2, x3)};
     *reinterpret_cast<u32x2*>(ab + 1 * (WIDE_GROUPS * 16 * 64) + off) = u32x2{wide_pack_hi16(r0, r1), wide_pack_hi16(r2, r3)};
+#ifdef NZ_ABLATE_WIDE_SPLIT
+    *reinterpret_cast<u32x2*>(ab + 2 * (WIDE_GROUPS * 16 * 64) + off) = u32x2{wide_pack_hi16(x0, r1), wide_pack_hi16(r2, x3)};
+#else
     *reinterpret_cast<u32x2*>(ab + 2 * (WIDE_GROUPS * 16 * 64) + off) =
         u32x2{wide_pack_hi16(r0 - wide_trunc(r0), r1 - wide_trunc(r1)), wide_pack_hi16(r2 - wide_trunc(r2), r3 - wide_trunc(r3))};
+#endif
   };
   auto stage_b = [&](int buf) {
     u32x4* fb = &sB[buf][0][0][0];
