@@ -1,3 +1,8 @@
+        if nodes_per_game is None:
+            # Nodes are never freed within a game (32 B each): every expansion adds its legal moves, a game lasts
+            # 50 (5x5) to 130+ (10x10) decisions.  Measured need at 200 sims/move: 400-640 nodes per simulation on
+            # the 5x5 fixtures, more than 1024 on 10x10.  A full arena is reported (NZ_ERR_OVERFLOW), never silent.
+            nodes_per_game = 1 + sims * (1024 + 48 * c.rows * c.cols)
 """SCS rules on the GPU as batch operators (C ABI nz_scs_*), plus the game-config loader.
 
 `ScsGameConfig` reads the reference's YAML game configs (Games/SCS/Game_configs/*.yml, parsed
@@ -154,8 +159,9 @@ class ScsSelfPlay:
         self.device = torch.device("cuda", device)
         self.n_games = n_games
         sims = int(search_config["Simulation"]["mcts_simulations"])
-        if nodes_per_game is None:      # nodes are never freed within a game: 40 children x sims x decisions
-            nodes_per_game = 1 + sims * 40 * 160
+        if nodes_per_game is None:      # nodes are never freed within a game (32 B each): children x sims x decisions.
+            nodes_per_game = 1 + sims * 2048    # 13 MB per game at 200 sims; measured use stays below a third of it on
+                                                # the 5x5 / 10x10 fixtures; a full arena is reported (NZ_ERR_OVERFLOW), never silent
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
         d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
