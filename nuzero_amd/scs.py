@@ -1,8 +1,87 @@
-        if nodes_per_game is None:
-            # Nodes are never freed within a game (32 B each): every expansion adds its legal moves, a game lasts
-            # 50 (5x5) to 130+ (10x10) decisions.  Measured need at 200 sims/move: 400-640 nodes per simulation on
-            # the 5x5 fixtures, more than 1024 on 10x10.  A full arena is reported (NZ_ERR_OVERFLOW), never silent.
-            nodes_per_game = 1 + sims * (1024 + 48 * c.rows * c.cols)
+"""SCS rules on the GPU as batch operators (C ABI nz_scs_*), plus the game-config loader.
+
+`ScsGameConfig` reads the reference's YAML game configs (Games/SCS/Game_configs/*.yml, parsed
+by SCS_Game.load_game_from_config, SCS_Game.py:1570-1779) with the "Detailed" map and
+victory-point methods; `ScsBatch` runs G independent games on the device: step, legal-move
+mask (possible_actions, :395-484), state image (generate_state, :1348-1505).
+"""
+import ctypes
+from ctypes import byref, c_int32, c_void_p
+
+import numpy as np
+import torch
+import yaml
+
+from . import _lib
+from ._lib import lib
+
+
+class ScsGameConfig:
+    def __init__(self, path_or_dict):
+        if isinstance(path_or_dict, dict):
+            d = path_or_dict
+        else:
+            with open(path_or_dict) as f:
+                d = yaml.safe_load(f)
+        self.rows, self.cols = int(d["Board_dimensions"]["rows"]), int(d["Board_dimensions"]["columns"])
+        self.turns, self.stacking = int(d["Turns"]), int(d["Stacking_limit"])
+        if d["Map"]["creation_method"] != "Detailed" or d["Victory_points"]["creation_method"] != "Detailed":
+            raise NotImplementedError("only 'Detailed' maps and victory points (the 'Randomized' methods draw "
+                                      "from numpy's global stream at load time, SCS_Game.py:1683-1738)")
+        units = {int(p["id"]): p for p in d["Units"].values()}
+        terrain = {int(p["id"]): p for p in d["Terrain"].values()}
+        tmap = np.asarray(d["Map"]["map_configuration"])
+        if tmap.shape != (self.rows, self.cols):
+            raise ValueError("Wrong shape for map configuration")
+        self.terrain = np.array([[terrain[int(t)]["attack_modifier"], terrain[int(t)]["defense_modifier"],
+                                  terrain[int(t)]["cost"]] for t in tmap.reshape(-1)], np.float32)
+        # the two halves of the board reinforcements may arrive on by default (define_board_sides, :1140-1158)
+        mid = self.cols // 2
+        if self.cols % 2:
+            p1_last, p2_first = mid - 1, mid + 1
+        else:
+            p1_last, p2_first = max(0, mid - 2), min(self.cols - 1, mid + 1)
+        arr = d["Reinforcements"]["arrival"]
+        rows_u, rows_a = [], []
+        for p, key in enumerate(("p1", "p2")):
+            sched = d["Reinforcements"]["schedule"][key]
+            if len(sched) != self.turns + 1:
+                raise ValueError("Reinforcement schedule should have 'turns + 1' entries")
+            k = 0
+            for turn, ids in enumerate(sched):
+                for uid in ids:
+                    u = units[int(uid)]
+                    a = np.zeros((self.rows, self.cols), np.uint8)
+                    if arr["method"] == "Default":
+                        if p == 0:
+                            a[:, :p1_last + 1] = 1
+                        else:
+                            a[:, p2_first:] = 1
+                    else:
+                        for (r, c) in arr["locations"][key][k]:
+                            a[r, c] = 1
+                        k += 1
+                    rows_u.append([p, turn, u["attack"], u["defense"], u["movement"]])
+                    rows_a.append(a.reshape(-1))
+        self.units = np.array(rows_u, np.int32)
+        self.arrival = np.array(rows_a, np.uint8)
+        vp = d["Victory_points"]["vp_locations"]
+        self.n_vp = (len(vp["p1"]), len(vp["p2"]))
+        self.vp = np.array(list(vp["p1"]) + list(vp["p2"]), np.int32).reshape(-1, 2)
+        s = self.stacking
+        self.planes = 1 + 6 * s + 1 + s + 1 + s + s
+        self.num_actions = self.planes * self.rows * self.cols
+        self.channels = 3 + 2 + 36 + 2 * 9 * s + 1 + s + 4 + 1 + 1
+
+
+class ScsBatch:
+    def __init__(self, config, n_games, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("nuzero_amd needs a ROCm GPU; there is no CPU fallback")
+        self.cfg = config if isinstance(config, ScsGameConfig) else ScsGameConfig(config)
+        c = self.cfg
+        self.device = torch.device("cuda", device)
+        self.n_games = n_games
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
         d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
@@ -75,9 +154,11 @@ class ScsSelfPlay:
         self.device = torch.device("cuda", device)
         self.n_games = n_games
         sims = int(search_config["Simulation"]["mcts_simulations"])
-        if nodes_per_game is None:      # nodes are never freed within a game (32 B each): children x sims x decisions.
-            nodes_per_game = 1 + sims * 2048    # 13 MB per game at 200 sims; measured use stays below a third of it on
-                                                # the 5x5 / 10x10 fixtures; a full arena is reported (NZ_ERR_OVERFLOW), never silent
+        if nodes_per_game is None:
+            # Nodes are never freed within a game (32 B each): every expansion adds its legal moves, a game lasts
+            # 50 (5x5) to 130+ (10x10) decisions.  Measured need at 200 sims/move: 400-640 nodes per simulation on
+            # the 5x5 fixtures, more than 1024 on 10x10.  A full arena is reported (NZ_ERR_OVERFLOW), never silent.
+            nodes_per_game = 1 + sims * (1024 + 48 * c.rows * c.cols)
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
         d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
