@@ -66,8 +66,9 @@ def main():
     ap.add_argument("--evaluator", choices=["native", "torch"], default="native")
     ap.add_argument("--loop", choices=["library", "python"], default="library",
                     help="library: nz_scs_search_play (native evaluator only); python: one host round trip per wave")
-    ap.add_argument("--nodes-per-sim", type=int, default=2048,
-                    help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game)")
+    ap.add_argument("--nodes-per-sim", type=int, default=0,
+                    help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game); "
+                         "0 = the engine's board-scaled default")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the concurrent games into this many independent sets, each with its own engine, network "
                          "buffers, host thread and HIP stream (native evaluator, library loop): their small kernels overlap")
@@ -138,7 +139,8 @@ def main():
                               "epsilon_random_exploration": 0.001, "value_factor": 1,
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
-    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=1 + args.sims * args.nodes_per_sim, device=local)
+    sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None,
+                     device=local)
     seeds = range(rank * args.games, (rank + 1) * args.games)       # game index = rank * games + g
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
@@ -155,7 +157,8 @@ def main():
             n_i = BoardNet(args.arch, cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
                            num_blocks=args.layers, kernel_size=3, max_batch=per, device=local, hex=args.hex)
             n_i.set_weights(w, args.iters)
-            sets.append((ScsSelfPlay(cfg, search, per, nodes_per_game=1 + args.sims * args.nodes_per_sim, device=local), n_i,
+            sets.append((ScsSelfPlay(cfg, search, per, device=local,
+                                     nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None), n_i,
                          torch.cuda.Stream(device=local)))
         results = [None] * S
 
