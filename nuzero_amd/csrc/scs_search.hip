@@ -372,10 +372,14 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       nodes[node].to_play = (int8_t)to_play;
     }
     slot = __shfl(slot, 0, 64);
+#ifndef NZ_ABLATE_SCS_MASK    // timing experiment: no legal mask (results wrong)
     scs_legal_mask_wave<MASK_WORDS>(R, sc, smask, lane);
+#endif
     uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
     for (int i = lane; i < MASK_WORDS; i += 64) m[i] = smask[i];
+#ifndef NZ_ABLATE_SCS_IMAGE   // timing experiment: no state image (results wrong)
     scs_state_image_wave(R, sc, images + (size_t)slot * R.channels * R.tiles, lane);
+#endif
     queued = true;
     break;
   }

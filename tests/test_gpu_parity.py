@@ -468,3 +468,27 @@ def test_position_cache_is_results_neutral():
         g.engine.close()
     for k in ("lengths", "outcomes", "actions", "visits", "child_prior", "child_value_sum", "states"):
         assert np.array_equal(out["disabled"][k], out["dict"][k]), k
+
+
+@pytest.mark.parametrize("gain,value_tol", [(0.05, 1e-5), (6.0, 1e-3)])
+def test_network_keeps_float32_range(net_kat, gain, value_tol):
+    """The split-bf16 arithmetic keeps float32's exponent range (an fp16 split would not): with tiny weights
+    (logits around 1e-6) and with large ones (logits around 2e4) the logits stay within 1e-5 of the oracle
+    relative to the largest logit.  Values: 1e-5 absolute for the small net (the kernel's tanh has an absolute
+    error of 3e-7, so a value of 5e-10 comes out as 0); the large net saturates its value head's tanh layers, which
+    turns the logit-level differences of ANY two float32 implementations (0.06 on 2e4 here) into 1e-4 on the value."""
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle.net import RecurrentNetRef
+    w = synthetic_recurrent_net_weights(4, 2, 1, 64, 2, True, gain)
+    eng = _engine(legacy_ttt_search_config(), 16)
+    eng.set_weights(w, recurrent_iterations=2)
+    x = _images(net_kat["codes"][::37])
+    logits, value, _ = eng.net_forward(x)
+    p, v = RecurrentNetRef(w, 2, 1, 64, 2).inference(np.asarray(x), 2)
+    p = p.reshape(len(x), -1)
+    scale = float(np.abs(p).max())
+    assert scale > 0 and np.isfinite(scale)
+    assert np.max(np.abs(logits.cpu().numpy() - p)) <= 1e-5 * scale
+    np.testing.assert_allclose(value.cpu().numpy(), v.reshape(-1), rtol=0, atol=value_tol)
+    eng.close()
