@@ -25,33 +25,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 
-def cpu_baseline(config_path, weights, layers, search, seconds):
-    """The CPU oracle (oracle/scs.py rules + oracle/search.py Explorer + oracle/net.py ConvNet, the
-    restatement of the reference's path) on a bounded sample: moves of one self-play game until
-    `seconds` have passed, one process, one torch thread."""
-    import torch
-    from oracle import search as osearch
-    from oracle.net import FeedForwardRef
-    from oracle.scs import ScsConfig, ScsGame
-    torch.set_num_threads(1)
-    net = FeedForwardRef(weights, "convnet", layers)
-    ev = osearch.net_evaluator(net, None)
-    game = ScsGame(ScsConfig(config_path))
-    explorer = osearch.Explorer(search, True, np.random.RandomState(0))
-    root = osearch.Node(0)
-    t0 = time.perf_counter()
-    moves = 0
-    while not game.is_terminal() and time.perf_counter() - t0 < seconds:
-        action, chosen, _ = explorer.run_mcts(game, ev, root)
-        game.step_index(action)
-        root = chosen
-        moves += 1
-    dt = time.perf_counter() - t0
-    return {"expansions_per_s": explorer.counters.expansions / dt, "simulations_per_s": explorer.counters.simulations / dt,
-            "moves_per_s": moves / dt, "cores": 1, "kind": "port",
-            "sample": "%d moves of one game (%d simulations) in %.1f s" % (moves, explorer.counters.simulations, dt)}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +45,6 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="split the concurrent games into this many independent sets, each with its own engine, network "
                          "buffers, host thread and HIP stream (native evaluator, library loop): their small kernels overlap")
-    ap.add_argument("--cpu-seconds", type=float, default=0.0, help="also time the CPU oracle for this long")
     ap.add_argument("--config", default=os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
     args = ap.parse_args()
     import torch
@@ -199,11 +171,6 @@ def main():
         td.destroy_process_group()
         return
     out = {}
-    if args.cpu_seconds > 0:
-        assert args.arch == "convnet", "the CPU baseline is written for ConvNet"
-        base = cpu_baseline(args.config, w, args.layers, search, args.cpu_seconds)
-        base["games_per_s_estimate"] = base["moves_per_s"] / float(r["lengths"].mean())
-        out["cpu_baseline"] = base
     native = args.evaluator == "native"
     print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, %s convs), %s evaluator, "
                                   "%s move loop" % (cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, net_name,

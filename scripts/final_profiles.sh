@@ -12,7 +12,7 @@ python3 $R/scripts/pmc_summary.py $(ls /tmp/p_n1/*/*counter_collection.csv | hea
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d /tmp/p_n2 -- python3 $R/scripts/net_only.py > $O/pmc_n2.log 2>&1 || exit 1
 python3 $R/scripts/pmc_summary.py $(ls /tmp/p_n2/*/*counter_collection.csv | head -1) "net_kernel" > $O/pmc_net_kernel_lds.txt
 cat $O/pmc_net_kernel_sq.txt $O/pmc_net_kernel_lds.txt
-timeout -k 10 400 python3 $R/bench_scs.py --games 1024 --cpu-seconds 15 > $O/scs_1024.log 2>&1 || exit 1
+timeout -k 10 400 python3 $R/bench_scs.py --games 1024 > $O/scs_1024.log 2>&1 || exit 1
 timeout -k 10 400 python3 $R/bench_scs.py --games 8192 --nodes-per-sim 1536 > $O/scs_8192.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_scs -- python3 $R/bench_scs.py --games 1024 > $O/scs_rocprof.log 2>&1 || exit 1
 cp $(ls /tmp/p_scs/*/*kernel_stats.csv | head -1) $O/scs_1024_kernel_stats.csv
