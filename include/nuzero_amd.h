@@ -360,6 +360,13 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
                                   int32_t recurrent_iterations);
 nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
                               float* logits_dev, float* probs_dev, float* value_dev, void* stream);
+/* The same without the layout conversion: the network's own input buffer is rows of `row_stride` floats, channels
+ * contiguous (zero beyond in_channels: never write there), row = ((position / 16) * rows*cols + cell) * 16 +
+ * position % 16.  A producer (the SCS search kernel) writes the positions' planes there directly, then calls
+ * nz_boardnet_forward_rows. */
+nz_status nz_boardnet_input_rows(nz_boardnet* h, float** rows_dev, int32_t* row_stride);
+nz_status nz_boardnet_forward_rows(nz_boardnet* h, int32_t n, const int32_t* n_dev, float* logits_dev, float* probs_dev,
+                                   float* value_dev, void* stream);
 /* algorithmic FLOPs of one position (taps that fall off the board are not counted) */
 int64_t nz_boardnet_flops(const nz_boardnet* h);
 nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* policy_channels, int32_t* rows,

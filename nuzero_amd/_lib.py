@@ -113,6 +113,8 @@ SIGNATURES = {
     "nz_boardnet_last_error": (c_char_p, [c_void_p]),
     "nz_boardnet_set_weights": (c_int32, [c_void_p, POINTER(c_void_p), c_int32, c_int32]),
     "nz_boardnet_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_boardnet_input_rows": (c_int32, [c_void_p, POINTER(c_void_p), POINTER(c_int32)]),
+    "nz_boardnet_forward_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_boardnet_flops": (c_int64, [c_void_p]),
     "nz_boardnet_dims": (c_int32, [c_void_p] + [POINTER(c_int32)] * 5),
     "nz_scs_search_play": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),

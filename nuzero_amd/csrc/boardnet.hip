@@ -794,9 +794,9 @@ nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* 
   return NZ_OK;
 }
 
-nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
-                              float* logits_dev, float* probs_dev, float* value_dev, void* stream) {
-  if (!h || !images_dev || !value_dev) return NZ_ERR_ARG;
+static nz_status forward_impl(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
+                               float* logits_dev, float* probs_dev, float* value_dev, void* stream) {
+  if (!h || !value_dev) return NZ_ERR_ARG;
   if (!h->ready) return bfail(h, NZ_ERR_STATE, "no weights set");
   if (n < 0 || n > h->max_batch) return bfail(h, NZ_ERR_ARG, "batch %d exceeds max_batch %d", n, h->max_batch);
   if (n == 0) return NZ_OK;
@@ -804,8 +804,9 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
   hipStream_t s = (hipStream_t)stream;
   const size_t total = (size_t)((n + 15) / 16 * 16) * h->hw * h->inp;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
-                     h->net.in_channels, h->inp, h->hw);
+  if (images_dev != nullptr)        // else: the caller filled the input rows itself (nz_boardnet_input_rows)
+    hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
+                       h->net.in_channels, h->inp, h->hw);
   for (const ConvOp& op : h->ops) {
     const PackedConv& pc = h->convs[&op - h->ops.data()];
     ConvArgs a;
@@ -830,6 +831,24 @@ nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n
                      logits_dev, probs_dev, value_dev);
   B_HIP(h, hipGetLastError());
   return NZ_OK;
+}
+
+nz_status nz_boardnet_forward(nz_boardnet* h, const float* images_dev, int32_t n, const int32_t* n_dev,
+                              float* logits_dev, float* probs_dev, float* value_dev, void* stream) {
+  if (!images_dev) return NZ_ERR_ARG;
+  return forward_impl(h, images_dev, n, n_dev, logits_dev, probs_dev, value_dev, stream);
+}
+
+nz_status nz_boardnet_input_rows(nz_boardnet* h, float** rows_dev, int32_t* row_stride) {
+  if (!h || !rows_dev || !row_stride) return NZ_ERR_ARG;
+  *rows_dev = h->buffers[0];
+  *row_stride = h->inp;
+  return NZ_OK;
+}
+
+nz_status nz_boardnet_forward_rows(nz_boardnet* h, int32_t n, const int32_t* n_dev, float* logits_dev, float* probs_dev,
+                                   float* value_dev, void* stream) {
+  return forward_impl(h, nullptr, n, n_dev, logits_dev, probs_dev, value_dev, stream);
 }
 
 }  // extern "C"

@@ -392,7 +392,14 @@ __device__ __forceinline__ void scs_legal_mask_wave(const ScsRules& r, const Scs
 }
 
 // img: [channels][tiles] float32 in global memory, fully written.
-__device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const ScsState& s, float* __restrict__ img, int lane) {
+// ROWS = false: img is [channels][tiles] (the NCHW image of one position).  ROWS = true: img points at the
+// position's first row of the network's input rows (boardnet.hip: row = cell * 16 + ..., `stride` floats per row,
+// channels contiguous), so element (c, t) lives at img[t * 16 * stride + c] -- the leaf batch is then already in
+// the layout the conv kernels read and needs no conversion pass.
+template <bool ROWS>
+__device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const ScsState& s, float* __restrict__ img, int stride,
+                                                     int lane) {
+  auto at = [&](int c, int t) -> float& { return ROWS ? img[(size_t)t * 16 * stride + c] : img[c * r.tiles + t]; };
   const Scs game(r, const_cast<ScsState&>(s));
   const int T = r.tiles, S = r.stacking;
   const int per_player = 3 * S * 3;
@@ -400,7 +407,7 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
             phase_base = att_base + S;
   // planes that are dense: written whole; every other plane is zero-filled first
   for (int i = lane; i < r.channels * T; i += 64) {
-    const int c = i / T, t = i - c * T;
+    const int c = ROWS ? i % r.channels : i / T, t = ROWS ? i / r.channels : i - (i / T) * T;
     float v = 0.0f;
     if (c < 3) v = r.terrain_f[t][c];
     else if (c >= phase_base) {
@@ -409,11 +416,11 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
       else if (k == 4) v = (float)((double)s.turn / (double)r.turns);
       else v = s.player == 1 ? -1.0f : 1.0f;
     }
-    img[i] = v;
+    at(c, t) = v;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
   for (int p = 0; p < 2; ++p)
-    if (lane < r.n_vp[p]) img[(3 + p) * T + r.vp[p][lane]] = 1.0f;
+    if (lane < r.n_vp[p]) at(3 + p, r.vp[p][lane]) = 1.0f;
   for (int p = 0; p < 2; ++p) {                 // the next three reinforcements of each player, schedule order
     const bool queued = lane < r.n_units && r.u_player[lane] == p && s.status[lane] == SCS_QUEUED;
     unsigned long long m = __ballot(queued);
@@ -424,11 +431,11 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
       const int o = 5 + p * 18 + shown * 6;
       for (int t = lane; t < T; t += 64) {
         if (r.arrival[u][t]) {
-          img[o * T + t] = (float)r.u_attack[u];
-          img[(o + 1) * T + t] = (float)r.u_defense[u];
-          img[(o + 2) * T + t] = (float)s.mov[u];
+          at(o, t) = (float)r.u_attack[u];
+          at(o + 1, t) = (float)r.u_defense[u];
+          at(o + 2, t) = (float)s.mov[u];
         }
-        img[(o + 3) * T + t] = img[(o + 4) * T + t] = img[(o + 5) * T + t] = (float)importance;
+        at(o + 3, t) = at(o + 4, t) = at(o + 5, t) = (float)importance;
       }
     }
   }
@@ -436,15 +443,15 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
     const int u = lane, st = s.status[u];
     if (st >= SCS_AVAILABLE && st <= SCS_ATTACKED) {
       const int o = unit_base + r.u_player[u] * per_player + st * S * 3 + game.level_of(u) * 3, t = s.tile[u];
-      img[o * T + t] = (float)r.u_attack[u];
-      img[(o + 1) * T + t] = (float)r.u_defense[u];
-      img[(o + 2) * T + t] = (float)s.mov[u];
+      at(o, t) = (float)r.u_attack[u];
+      at(o + 1, t) = (float)r.u_defense[u];
+      at(o + 2, t) = (float)s.mov[u];
     }
   }
-  if (lane == 0 && s.target >= 0) img[target_plane * T + s.target] = 1.0f;
+  if (lane == 0 && s.target >= 0) at(target_plane, s.target) = 1.0f;
   if (lane < s.n_attackers) {
     const int u = s.attackers[lane];
-    if (s.status[u] != SCS_DEAD) img[(att_base + game.level_of(u)) * T + s.tile[u]] = 1.0f;
+    if (s.status[u] != SCS_DEAD) at(att_base + game.level_of(u), s.tile[u]) = 1.0f;
   }
 }
 

@@ -67,6 +67,7 @@ struct SearchParams {
   int32_t* leaf_count;     // [1]
   int32_t* active_count;   // [1] games that are not done with their move after a wave
   int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
+  int32_t image_row_stride; // > 0: leaf images are written as input rows of a board net (floats per row), else NCHW
   int32_t* error_flag;
   int64_t* counters;       // [2] simulations, expansions
   // records [G][MAX_MOVES]...
@@ -378,7 +379,11 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
     for (int i = lane; i < MASK_WORDS; i += 64) m[i] = smask[i];
 #ifndef NZ_ABLATE_SCS_IMAGE   // timing experiment: no state image (results wrong)
-    scs_state_image_wave(R, sc, images + (size_t)slot * R.channels * R.tiles, lane);
+    if (p.image_row_stride > 0)       // straight into the network's input rows: group of 16 slots, then cell, then slot
+      scs_state_image_wave<true>(R, sc, images + ((size_t)(slot >> 4) * R.tiles * 16 + (slot & 15)) * p.image_row_stride,
+                                 p.image_row_stride, lane);
+    else
+      scs_state_image_wave<false>(R, sc, images + (size_t)slot * R.channels * R.tiles, 0, lane);
 #endif
     queued = true;
     break;
@@ -630,6 +635,7 @@ nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* lea
   hipStream_t s = (hipStream_t)stream;
   S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
   h->p.terminal_budget = 1 << 30;             // run on until a leaf needs an evaluation, as this API promises
+  h->p.image_row_stride = 0;                  // NCHW images for the caller
   hipLaunchKernelGGL(wave_kernel, dim3(h->n_games), dim3(64), 0, s, h->p, 2, (const float*)nullptr, (const float*)nullptr,
                      images_dev, leaf_game_dev);
   S_HIP(h, hipGetLastError());
@@ -677,6 +683,9 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
     return sfail(h, NZ_ERR_ARG, "network is %d planes -> %d planes on %dx%d, the game needs %d -> %d on %dx%d", nin, npol,
                  nrows, ncols, R.channels, R.planes, R.rows, R.cols);
   if (nmax < G) return sfail(h, NZ_ERR_ARG, "network max_batch %d < %d games", nmax, G);
+  float* net_rows = nullptr;                   // the leaf images go straight into the network's input rows
+  int32_t row_stride = 0;
+  if (nz_boardnet_input_rows(net, &net_rows, &row_stride) != NZ_OK) return sfail(h, NZ_ERR_ARG, "bad network handle");
   if (!h->images) {
     const bool ok = dalloc(h, &h->images, (size_t)G * R.channels * R.tiles) && dalloc(h, &h->probs, (size_t)G * A) &&
                     dalloc(h, &h->value, (size_t)G) && dalloc(h, &h->leaf_game, (size_t)G) &&
@@ -727,12 +736,13 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
       S_HIP(h, hipMemcpyAsync(h->uniforms, uni.data(), uni.size() * sizeof(double), hipMemcpyHostToDevice, s));
     }
     hipLaunchKernelGGL(begin_move_kernel, dim3(G), dim3(64), 0, s, h->p, h->noise);
+    h->p.image_row_stride = row_stride;
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     const int sims = h->cfg.mcts_simulations;
     for (int w = 0;; ++w) {
       S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
-      hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, h->images, h->leaf_game);
+      hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, net_rows, h->leaf_game);
       ++h->waves;
       if ((w & 7) == 7 || w >= sims - 1) {
         int32_t active = 0;
@@ -741,7 +751,7 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
         if (active == 0) break;
         if (w > sims + 2) return sfail(h, NZ_ERR_STATE, "internal: a move's searches did not finish in %d waves", w);
       }
-      if (nz_boardnet_forward(net, h->images, G, h->p.leaf_count, nullptr, h->probs, h->value, stream) != NZ_OK)
+      if (nz_boardnet_forward_rows(net, G, h->p.leaf_count, nullptr, h->probs, h->value, stream) != NZ_OK)
         return sfail(h, NZ_ERR_HIP, "network: %s", nz_boardnet_last_error(net));
     }
     st = nz_scs_search_end_move(h, h->uniforms, stream);
