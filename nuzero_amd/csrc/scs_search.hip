@@ -66,6 +66,7 @@ struct SearchParams {
   uint32_t* leaf_mask;     // [G][MASK_WORDS] legal actions at the pending leaf
   int32_t* leaf_count;     // [1]
   int32_t* active_count;   // [1] games that are not done with their move after a wave
+  int32_t* clear_counters; // the (leaf, active) pair of the NEXT wave, zeroed by this one (nullptr: the host zeroes)
   int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
   int32_t image_row_stride; // > 0: leaf images are written as input rows of a board net (floats per row), else NCHW
   int32_t* error_flag;
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   __shared__ float stotal;
   const int g = blockIdx.x;
   const int lane = lane_id();
+  if (g == 0 && lane == 0 && p.clear_counters != nullptr) { p.clear_counters[0] = 0; p.clear_counters[1] = 0; }
   if (p.real[g].terminal) return;
   const int A = p.rules->planes * p.rules->tiles;
   SNode* nodes = p.nodes + (size_t)g * p.cap;
@@ -487,6 +489,7 @@ struct nz_scs_search {
   int32_t *leaf_game = nullptr, *nchild = nullptr, *status = nullptr;
   double *noise = nullptr, *uniforms = nullptr;
   int64_t waves = 0;
+  int32_t* counters_base = nullptr;          // 4 ints: two (leaf, active) pairs
 };
 
 namespace {
@@ -567,7 +570,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   bool ok = dalloc(h, &rules, 1) && dalloc(h, &p.real, G) && dalloc(h, &p.scratch, G) &&
             dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
             dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
-            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 2) &&
+            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 4) &&
             dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 2) && dalloc(h, &bias, (size_t)p.tab_len) &&
             dalloc(h, &sq, (size_t)p.tab_len) && dalloc(h, &p.rec_action, GM) && dalloc(h, &p.rec_tree_size, GM) &&
             dalloc(h, &p.rec_children, GM) && dalloc(h, &p.rec_bias, GM) && dalloc(h, &p.rec_root_value_sum, GM) &&
@@ -586,6 +589,8 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
     return sfail(nullptr, NZ_ERR_HIP, "upload failed");
   }
   p.active_count = p.leaf_count + 1;
+  p.clear_counters = nullptr;
+  h->counters_base = p.leaf_count;
   p.rules = rules;
   p.bias_tab = bias;
   p.sqrt_tab = sq;
@@ -636,6 +641,7 @@ nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* lea
   S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
   h->p.terminal_budget = 1 << 30;             // run on until a leaf needs an evaluation, as this API promises
   h->p.image_row_stride = 0;                  // NCHW images for the caller
+  h->p.clear_counters = nullptr;
   hipLaunchKernelGGL(wave_kernel, dim3(h->n_games), dim3(64), 0, s, h->p, 2, (const float*)nullptr, (const float*)nullptr,
                      images_dev, leaf_game_dev);
   S_HIP(h, hipGetLastError());
@@ -683,6 +689,7 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
     return sfail(h, NZ_ERR_ARG, "network is %d planes -> %d planes on %dx%d, the game needs %d -> %d on %dx%d", nin, npol,
                  nrows, ncols, R.channels, R.planes, R.rows, R.cols);
   if (nmax < G) return sfail(h, NZ_ERR_ARG, "network max_batch %d < %d games", nmax, G);
+  int32_t* const counters = h->counters_base;
   float* net_rows = nullptr;                   // the leaf images go straight into the network's input rows
   int32_t row_stride = 0;
   if (nz_boardnet_input_rows(net, &net_rows, &row_stride) != NZ_OK) return sfail(h, NZ_ERR_ARG, "bad network handle");
@@ -737,11 +744,15 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
     }
     hipLaunchKernelGGL(begin_move_kernel, dim3(G), dim3(64), 0, s, h->p, h->noise);
     h->p.image_row_stride = row_stride;
+    S_HIP(h, hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), s));
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     const int sims = h->cfg.mcts_simulations;
     for (int w = 0;; ++w) {
-      S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
+      // two (leaf, active) counter pairs: wave w counts into pair w & 1 and zeroes the other one for wave w + 1
+      h->p.leaf_count = counters + 2 * (w & 1);
+      h->p.active_count = h->p.leaf_count + 1;
+      h->p.clear_counters = counters + 2 * ((w + 1) & 1);
       hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, net_rows, h->leaf_game);
       ++h->waves;
       if ((w & 7) == 7 || w >= sims - 1) {
@@ -757,6 +768,9 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
     st = nz_scs_search_end_move(h, h->uniforms, stream);
     if (st != NZ_OK) return st;
   }
+  h->p.leaf_count = counters;
+  h->p.active_count = counters + 1;
+  h->p.clear_counters = nullptr;
   return NZ_OK;
 }
 
