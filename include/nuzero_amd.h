@@ -379,6 +379,9 @@ nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* 
  * reference's order) and polls for the end of the move's searches every few waves.
  * Synchronises.  Read the games with nz_scs_search_export / nz_scs_search_status. */
 nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, void* stream);
+/* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
+ * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
+nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);
 /* simulation waves (kernel rounds) the last nz_scs_search_play took */
 nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves);
 

@@ -119,6 +119,7 @@ SIGNATURES = {
     "nz_boardnet_dims": (c_int32, [c_void_p] + [POINTER(c_int32)] * 5),
     "nz_scs_search_play": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_waves": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "nz_scs_search_phase_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

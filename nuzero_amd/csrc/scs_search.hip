@@ -67,10 +67,16 @@ struct SearchParams {
   int32_t* leaf_count;     // [1]
   int32_t* active_count;   // [1] games that are not done with their move after a wave
   int32_t* clear_counters; // the (leaf, active) pair of the NEXT wave, zeroed by this one (nullptr: the host zeroes)
+  // numpy's pairwise float32 sum over num_actions entries as a straight program: leaf blocks [pw_hi[b-1], pw_hi[b])
+  // in index order, eight strided partial sums up to pw_be[b] and the rest added one by one, then pw_merge[b]
+  // "left + right" merges of the block-sum stack (built on the host for this game's num_actions)
+  int32_t pw_blocks;
+  uint16_t pw_hi[48], pw_be[48];
+  uint8_t pw_merge[48];
   int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
   int32_t image_row_stride; // > 0: leaf images are written as input rows of a board net (floats per row), else NCHW
   int32_t* error_flag;
-  int64_t* counters;       // [2] simulations, expansions
+  int64_t* counters;       // [16] simulations, expansions; [2..7] shader ticks per phase of the NZ_SCS_STAMPS diagnostic build
   // records [G][MAX_MOVES]...
   int32_t* rec_action;
   int32_t* rec_tree_size;
@@ -103,35 +109,54 @@ __device__ __forceinline__ double child_score(const SearchParams& p, const SNode
   return (double)(conf + (float)q);
 }
 
-// numpy's float32 pairwise sum of an array that is zero except at the sorted positions idx[0..k)
-// (np.sum over all num_actions entries of `probs`, Explorer.py:169); adding a zero is exact, so
-// only the non-zero entries and the block structure matter
-__device__ float np_sum_sparse_f32(const int* idx, const float* val, int k, int lo, int hi) {
-  const int n = hi - lo;
-  int first = 0;
-  while (first < k && idx[first] < lo) ++first;
-  int last = first;
-  while (last < k && idx[last] < hi) ++last;
-  if (n < 8) {
-    float r = 0.0f;
-    for (int i = first; i < last; ++i) r = r + val[i];
-    return r;
-  }
-  if (n <= 128) {
-    float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int body_end = lo + (n - n % 8);
-    int i = first;
-    for (; i < last && idx[i] < body_end; ++i) {
-      const int j = (idx[i] - lo) & 7;
-      r[j] = r[j] + val[i];
+// numpy's float32 pairwise sum (np.sum over all num_actions entries of `probs`, Explorer.py:169) of an array that
+// is zero except at k sorted positions; adding a zero is exact, so only the non-zero entries and numpy's block
+// structure matter.  Wave-uniform: lane i holds the i-th non-zero entry (idx ascending, val), every lane walks the
+// block program of SearchParams (built on the host) with the entries broadcast by v_readlane -- no memory accesses.
+__device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, int idx, float val, int k) {
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f, st4 = 0.f, st5 = 0.f, st6 = 0.f, st7 = 0.f;   // block-sum stack
+  int sp = 0, i = 0, lo = 0;
+  auto entry_idx = [&](int j) { return __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(j)); };
+  auto entry_val = [&](int j) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), __builtin_amdgcn_readfirstlane(j)));
+  };
+  for (int b = 0; b < p.pw_blocks; ++b) {
+    const int hi = p.pw_hi[b], be = p.pw_be[b];
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f;
+    while (i < k) {
+      const int ix = entry_idx(i);
+      if (ix >= be) break;
+      const float v = entry_val(i);
+      const int j = (ix - lo) & 7;                     // adding 0.0f to the other seven is exact
+      r0 += j == 0 ? v : 0.f; r1 += j == 1 ? v : 0.f; r2 += j == 2 ? v : 0.f; r3 += j == 3 ? v : 0.f;
+      r4 += j == 4 ? v : 0.f; r5 += j == 5 ? v : 0.f; r6 += j == 6 ? v : 0.f; r7 += j == 7 ? v : 0.f;
+      ++i;
     }
-    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < last; ++i) res = res + val[i];
-    return res;
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    while (i < k) {
+      if (entry_idx(i) >= hi) break;
+      res = res + entry_val(i);
+      ++i;
+    }
+    for (int mrg = p.pw_merge[b];; --mrg) {            // push, then merge: left + right
+      switch (sp) {
+        case 0: st0 = res; break; case 1: st1 = res; break; case 2: st2 = res; break; case 3: st3 = res; break;
+        case 4: st4 = res; break; case 5: st5 = res; break; case 6: st6 = res; break; default: st7 = res; break;
+      }
+      ++sp;
+      if (mrg == 0) break;
+      float right, left;
+      switch (sp) {
+        case 2: left = st0; right = st1; break; case 3: left = st1; right = st2; break; case 4: left = st2; right = st3; break;
+        case 5: left = st3; right = st4; break; case 6: left = st4; right = st5; break; case 7: left = st5; right = st6; break;
+        default: left = st6; right = st7; break;
+      }
+      res = left + right;
+      sp -= 2;
+    }
+    lo = hi;
   }
-  int n2 = n / 2;
-  n2 -= n2 % 8;
-  return np_sum_sparse_f32(idx, val, k, lo, lo + n2) + np_sum_sparse_f32(idx, val, k, lo + n2, hi);
+  return st0;
 }
 __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 here (children of one node)
   if (n < 8) {
@@ -151,7 +176,10 @@ __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 he
 
 __global__ void search_reset_kernel(SearchParams p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g == 0) { *p.leaf_count = 0; *p.active_count = 0; *p.error_flag = 0; p.counters[0] = 0; p.counters[1] = 0; }
+  if (g == 0) {
+    *p.leaf_count = 0; *p.active_count = 0; *p.error_flag = 0;
+    for (int i = 0; i < 16; ++i) p.counters[i] = 0;
+  }
   if (g >= p.n_games) return;
   Scs(*p.rules, p.real[g]).reset();
   SNode& n = p.nodes[(size_t)g * p.cap];
@@ -214,10 +242,14 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   __shared__ ScsState sc;
   __shared__ uint32_t smask[MASK_WORDS];
   __shared__ int sidx[MAXC];
-  __shared__ float sval[MAXC];
-  __shared__ float stotal;
   const int g = blockIdx.x;
   const int lane = lane_id();
+#ifdef NZ_SCS_STAMPS     // diagnostic build: where a game's wave time goes (nz_scs_search_phase_ticks)
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
+#define NZ_STAMP(slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tk[slot] += now - ts; ts = now; }
+#else
+#define NZ_STAMP(slot)
+#endif
   if (g == 0 && lane == 0 && p.clear_counters != nullptr) { p.clear_counters[0] = 0; p.clear_counters[1] = 0; }
   if (p.real[g].terminal) return;
   const int A = p.rules->planes * p.rules->tiles;
@@ -253,20 +285,17 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
     } else {
       __syncthreads();
-      if (lane < k) sval[lane] = probs[(size_t)slot * A + sidx[lane]];
-      __syncthreads();
-      if (lane == 0) stotal = np_sum_sparse_f32(sidx, sval, k, 0, A);
-      __syncthreads();
-      if (stotal == 0.0f) {                 // probs += mask (Explorer.py:171-173)
-        if (lane < k) sval[lane] = sval[lane] + 1.0f;
-        __syncthreads();
-        if (lane == 0) stotal = np_sum_sparse_f32(sidx, sval, k, 0, A);
-        __syncthreads();
+      const int my_idx = lane < k ? sidx[lane] : 0x7fffffff;
+      float my_val = lane < k ? probs[(size_t)slot * A + my_idx] : 0.0f;
+      float total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
+      if (total == 0.0f) {                  // probs += mask (Explorer.py:171-173)
+        my_val = my_val + 1.0f;
+        total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
       }
       if (lane < k) {
         SNode c;
-        c.prior = (double)(sval[lane] / stotal);
-        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)sidx[lane];
+        c.prior = (double)(my_val / total);
+        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)my_idx;
         c.to_play = -1; c.prior_f64 = 0; c.terminal = 0; c.pad = 0;
         nodes[base + lane] = c;
       }
@@ -291,6 +320,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
+  NZ_STAMP(0);                                  // expansion + backup of the evaluated leaf
   if (!(mode & 2) || p.pending[g] >= 0) return;
   int sims_left = p.sims_left[g];
   if (sims_left <= 0) return;
@@ -301,6 +331,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     uint32_t* dst = reinterpret_cast<uint32_t*>(&R);
     for (int i = lane; i < (int)(sizeof(ScsRules) / 4); i += 64) dst[i] = src[i];
   }
+  NZ_STAMP(1);                                  // rules -> LDS
   const int root = p.root[g];
   long n_sim = 0;
   int budget = p.terminal_budget;
@@ -313,6 +344,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) dst[i] = src[i];
       __syncthreads();
     }
+    NZ_STAMP(2);                                // scratch game = real game
     int node = root, plen = 1;
     if (lane == 0) path[0] = root;
     bool bad = false;
@@ -345,6 +377,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       break;
     }
     __syncthreads();                          // lane 0's steps on the scratch game are visible to every lane
+    NZ_STAMP(3);                                // descent: scores, argmax, rule steps
     // evaluate (Explorer.py:137-181)
     const int to_play = sc.player, term = sc.terminal;
     if (term) {
@@ -388,8 +421,14 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       scs_state_image_wave<false>(R, sc, images + (size_t)slot * R.channels * R.tiles, 0, lane);
 #endif
     queued = true;
+    NZ_STAMP(4);                                // legal mask + state image of the queued leaf
     break;
   }
+  NZ_STAMP(5);                                  // terminal-leaf simulations
+#ifdef NZ_SCS_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)&p.counters[2 + i], tk[i]);
+#endif
   if (lane == 0) {
     p.sims_left[g] = sims_left;
     if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)n_sim);
@@ -558,6 +597,31 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.negate_player = 2;                       // Explorer.py:124; SCS players are 0 and 1
   p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
   p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
+  {   // numpy's pairwise_sum over num_actions float32 entries (np.sum in Explorer.py:169) as a block program
+    const int A = h->host_rules.planes * h->host_rules.tiles;
+    p.pw_blocks = 0;
+    bool fits = true;
+    struct Rec {
+      static void build(SearchParams& q, int lo, int hi, bool& ok) {
+        const int n = hi - lo;
+        if (n <= 128) {
+          if (q.pw_blocks >= 48) { ok = false; return; }
+          q.pw_hi[q.pw_blocks] = (uint16_t)hi;
+          q.pw_be[q.pw_blocks] = (uint16_t)(n < 8 ? lo : lo + (n - n % 8));
+          q.pw_merge[q.pw_blocks] = 0;
+          ++q.pw_blocks;
+          return;
+        }
+        int n2 = n / 2;
+        n2 -= n2 % 8;
+        build(q, lo, lo + n2, ok);
+        build(q, lo + n2, hi, ok);
+        if (ok) q.pw_merge[q.pw_blocks - 1] += 1;
+      }
+    };
+    Rec::build(p, 0, A, fits);
+    if (!fits) { nz_scs_search_destroy(h); return sfail(nullptr, NZ_ERR_ARG, "too many actions for the pairwise-sum program"); }
+  }
   p.terminal_budget = 1 << 30;
   p.frac = cfg->root_exploration_fraction;
   p.one_minus_frac = 1.0 - cfg->root_exploration_fraction;
@@ -571,7 +635,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
             dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
             dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
             dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 4) &&
-            dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 2) && dalloc(h, &bias, (size_t)p.tab_len) &&
+            dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 16) && dalloc(h, &bias, (size_t)p.tab_len) &&
             dalloc(h, &sq, (size_t)p.tab_len) && dalloc(h, &p.rec_action, GM) && dalloc(h, &p.rec_tree_size, GM) &&
             dalloc(h, &p.rec_children, GM) && dalloc(h, &p.rec_bias, GM) && dalloc(h, &p.rec_root_value_sum, GM) &&
             dalloc(h, &p.rec_child_action, GM * MAXC) && dalloc(h, &p.rec_child_visit, GM * MAXC) &&
@@ -771,6 +835,16 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
   h->p.leaf_count = counters;
   h->p.active_count = counters + 1;
   h->p.clear_counters = nullptr;
+  return NZ_OK;
+}
+
+// Diagnostic (library built with -DNZ_SCS_STAMPS; zeros otherwise): shader ticks summed over all games and waves
+// since the last reset -- out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations.
+nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host) {
+  if (!h || !out6_host) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  S_HIP(h, hipMemcpy(out6_host, h->p.counters + 2, 6 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return NZ_OK;
 }
 

@@ -259,6 +259,12 @@ class ScsSelfPlay:
         out["waves"] = int(waves.value)
         return out
 
+    def phase_ticks(self):
+        """Diagnostic build only (-DNZ_SCS_STAMPS): shader ticks per phase of the wave kernel, summed over games."""
+        out = (ctypes.c_int64 * 6)()
+        self._check(lib.nz_scs_search_phase_ticks(self._h, out))
+        return dict(zip(("expand", "rules_copy", "clone", "descent", "leaf_mask_image", "terminal_sims"), [int(v) for v in out]))
+
     def export(self):
         G, M, C = self.n_games, self.MAX_MOVES, self.MAX_CHILDREN
         dev = self.device
