@@ -70,6 +70,7 @@ struct SearchParams {
   // numpy's pairwise float32 sum over num_actions entries as a straight program: leaf blocks [pw_hi[b-1], pw_hi[b])
   // in index order, eight strided partial sums up to pw_be[b] and the rest added one by one, then pw_merge[b]
   // "left + right" merges of the block-sum stack (built on the host for this game's num_actions)
+  int32_t num_actions;
   int32_t pw_blocks;
   uint16_t pw_hi[48], pw_be[48];
   uint8_t pw_merge[48];
@@ -251,20 +252,39 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 #define NZ_STAMP(slot)
 #endif
   if (g == 0 && lane == 0 && p.clear_counters != nullptr) { p.clear_counters[0] = 0; p.clear_counters[1] = 0; }
-  if (p.real[g].terminal) return;
-  const int A = p.rules->planes * p.rules->tiles;
-  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  // everything this wave needs from the game's records in ONE round of loads (a chain of dependent loads, each
+  // behind the branch on the previous one, costs a memory round trip per link)
+  const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
   int32_t* path = p.path + (size_t)g * p.max_path;
+  const int terminal = p.real[g].terminal;
+  const int pend = p.pending[g];
+  const int plen_in = p.path_len[g];
+  const int base_in = p.node_count[g];
+  const int sims_in = p.sims_left[g];
+  const int root = p.root[g];
+  uint32_t mword[(MASK_WORDS + 63) / 64];
+#pragma unroll
+  for (int w = 0; w < (MASK_WORDS + 63) / 64; ++w) mword[w] = w * 64 + lane < MASK_WORDS ? m[w * 64 + lane] : 0u;
+  const int my_path0 = path[lane];                     // max_path > 64
+  if (terminal) return;
+  const int A = p.num_actions;
+  SNode* nodes = p.nodes + (size_t)g * p.cap;
 
-  if ((mode & 1) && p.pending[g] >= 0) {
-    const int slot = p.pending[g];
-    const int plen = p.path_len[g];
-    const int leaf = path[plen - 1];
+  const bool expanding = (mode & 1) && pend >= 0;
+  if (expanding) {
+    const int slot = pend;
+    const int plen = plen_in;
+    const int leaf = plen <= 64 ? __shfl(my_path0, plen - 1, 64) : path[plen - 1];
+    // second round: the evaluation and the path's statistics
+    const double v = (double)value[slot];
+    const int my_node = lane < plen ? my_path0 : 0;
+    const int my_visit = lane < plen ? nodes[my_node].visit : 0;
+    const double my_vs = lane < plen ? nodes[my_node].value_sum : 0.0;
     // legal actions in ascending order: lane w enumerates mask word w (and word 64 + w)
-    const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
     int k = 0;
-    for (int w0 = 0; w0 < MASK_WORDS; w0 += 64) {
-      uint32_t bits = w0 + lane < MASK_WORDS ? m[w0 + lane] : 0u;
+#pragma unroll
+    for (int w = 0; w < (MASK_WORDS + 63) / 64; ++w) {
+      uint32_t bits = mword[w];
       int inc = __popc(bits);
       for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(inc, d, 64);
@@ -274,12 +294,12 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       while (bits) {
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
-        if (off < MAXC) sidx[off] = (w0 + lane) * 32 + b;
+        if (off < MAXC) sidx[off] = (w * 64 + lane) * 32 + b;
         ++off;
       }
       k += __shfl(inc, 63, 64);
     }
-    const int base = p.node_count[g];
+    const int base = base_in;
     const bool overflow = k > MAXC;
     if (overflow || base + k > p.cap) {
       if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
@@ -307,13 +327,16 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     }
     if (lane == 0) {
       p.pending[g] = -1;
-      p.sims_left[g] -= 1;
+      p.sims_left[g] = sims_in - 1;
       atomicAdd((unsigned long long*)&p.counters[0], 1ull);
       atomicAdd((unsigned long long*)&p.counters[1], 1ull);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const double v = (double)value[slot];
-    for (int i = lane; i < plen; i += 64) {
+    // backup (Explorer.py:132-135): the path's statistics were read above; the leaf's new children do not touch them
+    if (lane < plen) {
+      nodes[my_node].visit = my_visit + 1;
+      nodes[my_node].value_sum = my_vs + v;
+    }
+    for (int i = 64 + lane; i < plen; i += 64) {
       SNode& n = nodes[path[i]];
       n.visit += 1;
       n.value_sum = n.value_sum + v;
@@ -321,8 +344,8 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   NZ_STAMP(0);                                  // expansion + backup of the evaluated leaf
-  if (!(mode & 2) || p.pending[g] >= 0) return;
-  int sims_left = p.sims_left[g];
+  if (!(mode & 2) || (pend >= 0 && !expanding)) return;
+  int sims_left = expanding ? sims_in - 1 : sims_in;
   if (sims_left <= 0) return;
 
   {
@@ -332,7 +355,6 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     for (int i = lane; i < (int)(sizeof(ScsRules) / 4); i += 64) dst[i] = src[i];
   }
   NZ_STAMP(1);                                  // rules -> LDS
-  const int root = p.root[g];
   long n_sim = 0;
   int budget = p.terminal_budget;
   bool queued = false;
@@ -599,6 +621,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
   {   // numpy's pairwise_sum over num_actions float32 entries (np.sum in Explorer.py:169) as a block program
     const int A = h->host_rules.planes * h->host_rules.tiles;
+    p.num_actions = A;
     p.pw_blocks = 0;
     bool fits = true;
     struct Rec {
