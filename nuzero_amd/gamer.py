@@ -94,10 +94,12 @@ class Gamer:
         """Arguments up to `size_estimate` are the reference's (Gamer.py:20).
         `shared_storage` is anything with ``get()`` returning a Network_Manager (or
         the Network_Manager itself); `buffer` anything with ``save_game(game, i)``
-        or None.  `game_class` must be Tic_Tac_Toe (by name) in this release."""
+        or None.  `game_class` is Tic_Tac_Toe or SCS_Game (recognised by name); for SCS `game_args[0]` is
+        the game config file and all `num_games` games of a round run concurrently."""
         name = getattr(game_class, "__name__", str(game_class)).lower()
-        if "tic" not in name and "ttt" not in name:
-            raise NotImplementedError(f"game {name!r}: only Tic_Tac_Toe runs on the GPU engine so far")
+        self.is_scs = "scs" in name
+        if not self.is_scs and "tic" not in name and "ttt" not in name:
+            raise NotImplementedError(f"game {name!r}: Tic_Tac_Toe and SCS_Game run on the GPU engine")
         if cache_choice not in ("disabled", None, "dict", "keyless"):
             raise ValueError(f"bad cache_choice {cache_choice!r}")          # general_utils.py:14-24
         self.cache_choice = cache_choice if cache_choice else "disabled"
@@ -108,9 +110,22 @@ class Gamer:
         self.num_games = num_games
         self.base_seed = base_seed
         self.time_to_stop = False
+        self.device = device
+        self._loaded = None
+        if self.is_scs:
+            # game_args = [config path] as for SCS_Game(cfg) (Games/SCS/SCS_Game.py:45); every game of the round runs
+            # concurrently; the inference cache of the reference has no device counterpart here
+            from .scs import ScsGameConfig, ScsSelfPlay
+            if not game_args:
+                raise ValueError("SCS needs game_args = [path of the game config]")
+            if self.cache_choice != "disabled":
+                raise NotImplementedError("SCS: cache_choice must be 'disabled'")
+            self.scs_config = ScsGameConfig(game_args[0])
+            self.engine = ScsSelfPlay(self.scs_config, search_config, num_games, training=True, device=device)
+            self._board_net = None
+            return
         self.engine = SelfPlayEngine(search_config, num_games, training=True, device=device,
                                      n_slots=concurrent_games or num_games)
-        self._loaded = None
 
     def _network(self):
         nm = self.shared_storage.get() if hasattr(self.shared_storage, "get") else self.shared_storage
@@ -120,6 +135,8 @@ class Gamer:
 
     def play_games(self):
         """One self-play round: `num_games` games.  Returns (records, stats list)."""
+        if self.is_scs:
+            return self._play_scs_games()
         nm = self._network() if self.shared_storage is not None else None
         if nm is not None and self._loaded is not nm:
             s = nm.spec()
@@ -135,6 +152,24 @@ class Gamer:
         r = self.engine.export()
         records = [GameRecord(r["states"][g], r["visits"][g], r["actions"][g], r["lengths"][g], r["outcomes"][g])
                    for g in range(self.num_games)]
+        stats = [game_stats(r, g) for g in range(self.num_games)]
+        if self.buffer is not None:
+            for rec in records:
+                self.buffer.save_game(rec, self.game_index)
+        return records, stats
+
+    def _play_scs_games(self):
+        from .scs import scs_game_records
+        nm = self._network()
+        if self._loaded is not nm:
+            if self._board_net is not None:
+                self._board_net.close()
+            c = self.scs_config
+            self._board_net = nm.board_net(c.rows, c.cols, self.num_games, self.recurrent_iterations, self.device)
+            self._loaded = nm
+        r = self.engine.play_native(self._board_net, range(self.base_seed, self.base_seed + self.num_games))
+        self.base_seed += self.num_games
+        records = scs_game_records(self.engine, r)
         stats = [game_stats(r, g) for g in range(self.num_games)]
         if self.buffer is not None:
             for rec in records:

@@ -17,30 +17,34 @@ class RecurrentNetSpec:
     (Neural_Networks/Architectures/RecurrentNet.py:18-79) as plain numbers."""
 
     def __init__(self, in_channels=2, policy_channels=1, width=64, num_blocks=2, recall=True,
-                 value_activation="tanh", arch="recurrent", kernel_size=3):
+                 value_activation="tanh", arch="recurrent", kernel_size=3, hex=False):
         self.in_channels, self.policy_channels = in_channels, policy_channels
         self.width, self.num_blocks, self.recall = width, num_blocks, recall
         self.value_activation = value_activation
         self.arch, self.kernel_size = arch, kernel_size      # "recurrent" | "resnet" | "convnet"
+        self.hex = hex                                        # every conv a hexagdly.Conv2d(kernel_size=1): board nets only
 
     @classmethod
     def from_state_dict(cls, sd, value_activation="tanh"):
-        """Recognise RecurrentNet / ResNet / ConvNet (hex=False) by their parameter names."""
-        policy_channels = int(sd["policy_head.layers.2.weight"].shape[0])
-        n_block_convs = sum(1 for k in sd if ".before_shortcut." in k)
-        if "projection.0.weight" in sd:
-            first = sd["projection.0.weight"]
+        """Recognise RecurrentNet / ResNet / ConvNet by their parameter names; hex=True models hold
+        `<layer>.kernel0` / `<layer>.kernel1` (hexagdly.Conv2d) where square ones hold `<layer>.weight`."""
+        hexnet = "policy_head.layers.2.kernel0" in sd
+        suffix = "kernel0" if hexnet else "weight"
+        policy_channels = int(sd["policy_head.layers.2." + suffix].shape[0])
+        n_block_convs = sum(1 for k in sd if ".before_shortcut." in k and k.endswith(suffix))
+        if "projection.0." + suffix in sd:
+            first = sd["projection.0." + suffix]
             return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_block_convs // 2,
-                       "recur_module.0.weight" in sd, value_activation, "recurrent", 3)
-        if "input_block.0.weight" in sd:
-            first = sd["input_block.0.weight"]
+                       "recur_module.0." + suffix in sd, value_activation, "recurrent", 3, hexnet)
+        if "input_block.0." + suffix in sd:
+            first = sd["input_block.0." + suffix]
             return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_block_convs // 2, False,
-                       value_activation, "resnet", 3)
-        if "general_module.0.weight" in sd:
-            first = sd["general_module.0.weight"]
-            n_layers = sum(1 for k in sd if k.startswith("general_module.")) - 1
+                       value_activation, "resnet", 3, hexnet)
+        if "general_module.0." + suffix in sd:
+            first = sd["general_module.0." + suffix]
+            n_layers = sum(1 for k in sd if k.startswith("general_module.") and k.endswith(suffix)) - 1
             return cls(int(first.shape[1]), policy_channels, int(first.shape[0]), n_layers, False,
-                       value_activation, "convnet", int(first.shape[2]))
+                       value_activation, "convnet", 1 if hexnet else int(first.shape[2]), hexnet)
         raise ValueError("unrecognised network: expected RecurrentNet, ResNet or ConvNet parameter names")
 
 
@@ -84,15 +88,42 @@ class Network_Manager:
         kernel the search uses (Network_Manager.py:46-64, eval/no_grad branch)."""
         if training:
             raise NotImplementedError("the engine only evaluates; training stays in PyTorch")
+        s = self._spec
+        rows, cols = int(state.shape[-2]), int(state.shape[-1])
+        if (s.in_channels, s.policy_channels, rows, cols, s.hex) != (2, 1, 3, 3, False):
+            return self._board_inference(state, iters_to_do, rows, cols)
         from .engine import SelfPlayEngine
         from .search_config import legacy_ttt_search_config
         if self._engine is None or self._engine.net_spec["iters"] != iters_to_do:
             if self._engine is None:
                 self._engine = SelfPlayEngine(legacy_ttt_search_config(), 16)
-            s = self._spec
             self._engine.set_weights(self._sd, width=s.width, num_blocks=s.num_blocks, recall=s.recall,
                                      value_activation=s.value_activation, recurrent_iterations=iters_to_do,
                                      arch=s.arch, kernel_size=s.kernel_size)
         logits, value, _ = self._engine.net_forward(state, want_probs=False)
         b = logits.shape[0]
         return logits.reshape(b, self._spec.policy_channels, 3, 3), value.reshape(b, 1)
+
+    def board_net(self, rows, cols, max_batch, recurrent_iterations=1, device=0):
+        """The model as a nuzero_amd.boardnet.BoardNet for rows x cols boards (SCS): the network the
+        SCS self-play path evaluates on the device."""
+        from .boardnet import BoardNet
+        s = self._spec
+        net = BoardNet(s.arch, s.in_channels, s.policy_channels, rows, cols, width=s.width, num_blocks=s.num_blocks,
+                       recall=s.recall, value_activation=s.value_activation, kernel_size=s.kernel_size,
+                       max_batch=max_batch, device=device, hex=s.hex)
+        net.set_weights(self._sd, recurrent_iterations or 1)
+        return net
+
+    def _board_inference(self, state, iters_to_do, rows, cols):
+        x = torch.as_tensor(state, dtype=torch.float32)
+        key = (rows, cols, iters_to_do, max(int(x.shape[0]), 16))
+        if getattr(self, "_board", None) is None or self._board[0] != key:
+            if getattr(self, "_board", None) is not None:
+                self._board[1].close()
+            self._board = (key, self.board_net(rows, cols, key[3], iters_to_do))
+        net = self._board[1]
+        x = x.to(net.device).contiguous()
+        _, value, logits = net.forward(x, want_logits=True)
+        b = x.shape[0]
+        return logits.reshape(b, self._spec.policy_channels, rows, cols), value.reshape(b, 1)
