@@ -312,7 +312,9 @@ nz_status nz_scs_status(nz_scs* h, int32_t* status_dev, void* stream);
  *   repeat: select(images [G][C][R][Cc], leaf_game [G], &n) ; if n == 0 break ;
  *           evaluate images[0..n) ; expand(probs [n][A], value [n])
  *   end_move(uniforms [G][3])
- * nodes_per_game sizes each game's tree arena (nodes are never freed within a game). */
+ * nodes_per_game sizes each game's tree arena: two halves; at every re-root the new root's subtree is copied
+ * into the other half (the rest of the tree is dropped), so a half must hold the kept subtree plus one move's
+ * expansions (32 bytes per node; a full half is reported as NZ_ERR_OVERFLOW). */
 typedef struct nz_scs_search nz_scs_search;
 nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* desc, const nz_search_cfg* cfg,
                                int32_t n_games, int32_t nodes_per_game, int32_t device);

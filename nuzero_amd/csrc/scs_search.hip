@@ -56,7 +56,9 @@ struct SearchParams {
   const ScsRules* rules;
   ScsState* real;          // [G]
   ScsState* scratch;       // [G]
-  SNode* nodes;            // [G][cap]
+  SNode* nodes;            // [G][2][half_cap]: two halves per game, the live tree is in half `half[g]`
+  int8_t* half;            // [G]
+  int32_t half_cap;
   int32_t* node_count;     // [G]
   int32_t* root;           // [G]
   int32_t* sims_left;      // [G]
@@ -175,6 +177,11 @@ __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 he
   return res;
 }
 
+// the half of game g's arena that holds its live tree
+__device__ __forceinline__ SNode* arena(const SearchParams& p, int g) {
+  return p.nodes + (size_t)g * p.cap + (size_t)p.half[g] * p.half_cap;
+}
+
 __global__ void search_reset_kernel(SearchParams p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g == 0) {
@@ -183,6 +190,7 @@ __global__ void search_reset_kernel(SearchParams p) {
   }
   if (g >= p.n_games) return;
   Scs(*p.rules, p.real[g]).reset();
+  p.half[g] = 0;
   SNode& n = p.nodes[(size_t)g * p.cap];
   n.prior = 0.0; n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = 0;
   n.to_play = -1; n.prior_f64 = 0; n.terminal = 0; n.pad = 0;
@@ -202,7 +210,7 @@ __global__ void search_reset_kernel(SearchParams p) {
 __global__ void root_children_kernel(SearchParams p, int32_t* out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= p.n_games) return;
-  out[g] = p.real[g].terminal ? 0 : p.nodes[(size_t)g * p.cap + p.root[g]].n_children;
+  out[g] = p.real[g].terminal ? 0 : arena(p, g)[p.root[g]].n_children;
 }
 
 // add_exploration_noise (Explorer.py:201-210) and the start of a move's search
@@ -210,7 +218,7 @@ __global__ void begin_move_kernel(SearchParams p, const double* __restrict__ noi
   const int g = blockIdx.x;
   const int lane = lane_id();
   if (p.real[g].terminal) return;
-  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  SNode* nodes = arena(p, g);
   const SNode& root = nodes[p.root[g]];
   if (p.training && lane < root.n_children) {
     SNode& c = nodes[root.child_base + lane];
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   const int my_path0 = path[lane];                     // max_path > 64
   if (terminal) return;
   const int A = p.num_actions;
-  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  SNode* nodes = arena(p, g);
 
   const bool expanding = (mode & 1) && pend >= 0;
   if (expanding) {
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     }
     const int base = base_in;
     const bool overflow = k > MAXC;
-    if (overflow || base + k > p.cap) {
+    if (overflow || base + k > p.half_cap) {
       if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
     } else {
       __syncthreads();
@@ -474,7 +482,7 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
   ScsState& real = p.real[g];
   if (real.terminal) return;
   const ScsRules& R = *p.rules;
-  SNode* nodes = p.nodes + (size_t)g * p.cap;
+  SNode* nodes = arena(p, g);
   const SNode root = nodes[p.root[g]];
   const int k = root.n_children, move = real.length;
   if (k == 0 || p.sims_left[g] != 0 || p.pending[g] >= 0 || move >= MAX_MOVES) {
@@ -536,6 +544,50 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
   p.root[g] = root.child_base + chosen_child;
 }
 
+// Re-rooting (Gamer.py:78-79) with the dead part of the tree dropped: the subtree of the new root is copied
+// breadth-first into the other half of the game's arena (a node's children stay one contiguous block in the same
+// order, so nothing observable changes), the old half is free for the move after next.  One wavefront per game:
+// lane i takes the i-th node of the current BFS window and copies its block of children.
+__global__ __launch_bounds__(64) void compact_kernel(SearchParams p) {
+  const int g = blockIdx.x;
+  const int lane = lane_id();
+  if (p.real[g].terminal) return;
+  const SNode* src = arena(p, g);
+  SNode* dst = p.nodes + (size_t)g * p.cap + (size_t)(p.half[g] ^ 1) * p.half_cap;
+  if (lane == 0) dst[0] = src[p.root[g]];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  int count = 1, head = 0;
+  while (head < count) {
+    const int window = count - head < 64 ? count - head : 64;     // nodes whose children are copied this round
+    const int i = head + lane;
+    int k = 0, cb = 0;
+    if (lane < window) { k = dst[i].n_children; cb = dst[i].child_base; }
+    int inc = k;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    const int total = __shfl(inc, 63, 64);
+    if (count + total > p.half_cap) {                  // uniform
+      if (lane == 0) atomicOr(p.error_flag, 1);
+      return;
+    }
+    if (k > 0) {
+      const int at = count + inc - k;
+      for (int j = 0; j < k; ++j) dst[at + j] = src[cb + j];
+      dst[i].child_base = at;
+    }
+    count += total;
+    head += window;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  if (lane == 0) {
+    p.half[g] ^= 1;
+    p.root[g] = 0;
+    p.node_count[g] = count;
+  }
+}
+
 }  // namespace
 
 struct nz_scs_search {
@@ -595,7 +647,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
                                int32_t nodes_per_game, int32_t device) {
   if (!out || !d || !cfg) return sfail(nullptr, NZ_ERR_ARG, "null argument");
   *out = nullptr;
-  if (n_games <= 0 || cfg->mcts_simulations <= 0 || nodes_per_game < 2) return sfail(nullptr, NZ_ERR_ARG, "bad sizes");
+  if (n_games <= 0 || cfg->mcts_simulations <= 0 || nodes_per_game < 4) return sfail(nullptr, NZ_ERR_ARG, "bad sizes");
   if (!cfg->keep_subtree) return sfail(nullptr, NZ_ERR_ARG, "keep_subtree = False is not supported (Gamer.py:78-79)");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
@@ -612,7 +664,8 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   memset(&p, 0, sizeof(p));
   const size_t G = n_games;
   p.n_games = n_games;
-  p.cap = nodes_per_game;
+  p.cap = nodes_per_game & ~1;                // two halves (compact_kernel)
+  p.half_cap = p.cap / 2;
   p.sims = cfg->mcts_simulations;
   p.training = cfg->training;
   p.softmax_moves = cfg->number_of_softmax_moves;
@@ -655,7 +708,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   double *bias = nullptr, *sq = nullptr;
   const size_t GM = G * MAX_MOVES;
   bool ok = dalloc(h, &rules, 1) && dalloc(h, &p.real, G) && dalloc(h, &p.scratch, G) &&
-            dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
+            dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.half, G) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
             dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
             dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 4) &&
             dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 16) && dalloc(h, &bias, (size_t)p.tab_len) &&
@@ -752,6 +805,7 @@ nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, v
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(end_move_kernel, dim3((h->n_games + 63) / 64), dim3(64), 0, s, h->p, uniforms_dev);
+  hipLaunchKernelGGL(compact_kernel, dim3(h->n_games), dim3(64), 0, s, h->p);
   S_HIP(h, hipGetLastError());
   return check_flag(h, s);
 }

@@ -155,10 +155,10 @@ class ScsSelfPlay:
         self.n_games = n_games
         sims = int(search_config["Simulation"]["mcts_simulations"])
         if nodes_per_game is None:
-            # Nodes are never freed within a game (32 B each): every expansion adds its legal moves, a game lasts
-            # 50 (5x5) to 130+ (10x10) decisions.  Measured need at 200 sims/move: 400-640 nodes per simulation on
-            # the 5x5 fixtures, more than 1024 on 10x10.  A full arena is reported (NZ_ERR_OVERFLOW), never silent.
-            nodes_per_game = 1 + sims * (1024 + 48 * c.rows * c.cols)
+            # Two halves (32 B per node): at every re-root the kept subtree is copied to the other half, so a half
+            # holds the kept subtree plus one move's expansions (<= 64 children each).  A full half is reported
+            # (NZ_ERR_OVERFLOW), never silent.
+            nodes_per_game = 2 * (1 + sims * 160)
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
         d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
