@@ -1,5 +1,7 @@
 """The oracle (oracle/) against the golden vectors made from the genuine
 reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -215,3 +217,31 @@ def test_board_sized_nets_against_reference(net_kat3, name):
         assert np.array_equal(p.reshape(-1), kat[f"{name}_logits"][i])
         assert np.array_equal(softmax(p).reshape(-1), kat[f"{name}_probs"][i])
         assert np.float32(v.reshape(-1)[0]) == kat[f"{name}_value"][i]
+
+
+@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+def test_hex_nets_against_reference(name):
+    """Pins oracle/net.py HexNetRef to the reference's hex=True nets -- once tests/golden/net_kat_hex.npz exists
+    (tests/golden/make_golden_hex.py needs the real hexagdly package, which the build container lacks: until
+    then hex parity is UNPINNED and this test is skipped)."""
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "net_kat_hex.npz")
+    if not os.path.exists(path):
+        pytest.skip("net_kat_hex.npz missing: hexagdly was not available to generate it (hex parity unpinned)")
+    from conftest import NETS3, nets3_inputs
+    from nuzero_amd.weights import (synthetic_weights, hex_param_shapes, recurrent_net_param_shapes, resnet_param_shapes,
+                                    convnet_param_shapes)
+    from oracle.net import HexNetRef
+    kat = np.load(path)
+    arch, seed, cin, planes, rows, cols, width, depth, recall, vact, iters, n, gain = NETS3[name]
+    if arch == "recurrent":
+        shapes = recurrent_net_param_shapes(cin, planes, width, depth, recall)
+    elif arch == "resnet":
+        shapes = resnet_param_shapes(cin, planes, width, depth)
+    else:
+        shapes = convnet_param_shapes(cin, planes, 3, width, depth)
+    w = synthetic_weights(100 + seed, hex_param_shapes(shapes), gain)
+    p, v = HexNetRef(w, arch, depth, recall, vact).inference(nets3_inputs(name), iters)
+    scale = np.abs(kat[f"{name}_logits"]).max(axis=1, keepdims=True) + 1.0
+    assert np.max(np.abs(p.reshape(n, -1) - kat[f"{name}_logits"]) / scale) < 1e-5
+    assert np.max(np.abs(v.reshape(-1) - kat[f"{name}_value"])) < 1e-5
