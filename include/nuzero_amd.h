@@ -381,6 +381,11 @@ nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* 
  * reference's order) and polls for the end of the move's searches every few waves.
  * Synchronises.  Read the games with nz_scs_search_export / nz_scs_search_status. */
 nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, void* stream);
+/* As nz_scs_search_play, stopping after `max_moves` decisions of every game (<= 0: play to the end): the
+ * first moves of a game are exactly those of the full game (Gamer.py:64-79 has no look-ahead), so this
+ * bounds a check on a large board / a heavy network without changing what is checked. */
+nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int32_t max_moves,
+                                   void* stream);
 /* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
  * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
 nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);

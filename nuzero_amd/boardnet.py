@@ -76,6 +76,20 @@ class BoardNet:
             c_void_p(value.data_ptr()), c_void_p(torch.cuda.current_stream().cuda_stream)))
         return (probs, value, logits) if want_logits else (probs, value)
 
-    def evaluator(self):
-        """For ScsSelfPlay.play: images -> (probs, values)."""
-        return lambda images: self.forward(images.contiguous())
+    def evaluator(self, fixed_batch=None):
+        """For ScsSelfPlay.play: images -> (probs, values).  With `fixed_batch` every call is launched for that many
+        positions with the live count in device memory -- the launch shapes (and with them the kernel chosen per
+        layer) of the in-library move loop, nz_scs_search_play, at fixed_batch = its number of games."""
+        if fixed_batch is None:
+            return lambda images: self.forward(images.contiguous())
+        buf = torch.zeros((int(fixed_batch), self.in_channels, self.rows, self.cols), dtype=torch.float32,
+                          device=self.device)
+        n_dev = torch.zeros((1,), dtype=torch.int32, device=self.device)
+
+        def ev(images):
+            n = images.shape[0]
+            buf[:n].copy_(images)
+            n_dev.fill_(n)
+            probs, value = self.forward(buf, n_dev=n_dev)
+            return probs[:n], value[:n]
+        return ev

@@ -628,7 +628,10 @@ void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
   const int wide_tiles = ((a.n_host + 15) / 16 + WIDE_GROUPS - 1) / WIDE_GROUPS * a.hw * (ntiles / WIDE_NT);
   // one workgroup per tile and per CU: below ~160 tiles the chip is too empty and the per-wavefront kernel wins
   // (w256 5x5: 512 positions = 100 tiles 53 vs 59 TFLOP/s, 1024 = 200 tiles 96 vs 81; w128: 100 tiles 50 vs 58, 400 tiles 91 vs 81)
-  if (a.ws != nullptr && (force_wide < 0 ? wide_tiles >= 160 : force_wide != 0)) {
+  // ... and a tile is 256 positions of one cell: with fewer than half of them live (a handful of games on a big board)
+  // most of its MFMAs multiply padding, and the per-wavefront kernel wins again
+  const bool tiles_filled = (a.n_host + 15) / 16 >= WIDE_GROUPS / 2;
+  if (a.ws != nullptr && (force_wide < 0 ? (wide_tiles >= 160 && tiles_filled) : force_wide != 0)) {
     const int groups = (a.n_host + 15) / 16;
     dim3 grid((groups + WIDE_GROUPS - 1) / WIDE_GROUPS * a.hw, ntiles / WIDE_NT);
     if (a.hex) hipLaunchKernelGGL(conv_wide_kernel<true>, grid, dim3(256), 0, s, a);

@@ -818,6 +818,11 @@ nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stre
 // only draws each move's random numbers (numpy RandomState streams, one per game, in the
 // reference's order) and checks every few waves whether the move's searches are complete.
 nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, void* stream) {
+  return nz_scs_search_play_moves(h, net, seeds_host, 0, stream);
+}
+
+nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int32_t max_moves,
+                                   void* stream) {
   if (!h || !net || (h->cfg.training && !seeds_host)) return sfail(h, NZ_ERR_ARG, "null argument");
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
@@ -854,7 +859,8 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
   if (st != NZ_OK) return st;
   h->waves = 0;
   const dim3 grid1((G + 127) / 128), block1(128);
-  for (int move = 0; move < MAX_MOVES; ++move) {
+  const int move_limit = max_moves > 0 && max_moves < MAX_MOVES ? max_moves : MAX_MOVES;
+  for (int move = 0; move < move_limit; ++move) {
     hipLaunchKernelGGL(search_status_kernel, grid1, block1, 0, s, h->p, h->status);
     if (h->cfg.training) hipLaunchKernelGGL(root_children_kernel, grid1, block1, 0, s, h->p, h->nchild);
     S_HIP(h, hipMemcpyAsync(status.data(), h->status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));

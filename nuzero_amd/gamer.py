@@ -112,6 +112,7 @@ class Gamer:
         self.time_to_stop = False
         self.device = device
         self._loaded = None
+        self._wrapped = None
         if self.is_scs:
             # game_args = [config path] as for SCS_Game(cfg) (Games/SCS/SCS_Game.py:45); every game of the round runs
             # concurrently; the inference cache of the reference has no device counterpart here
@@ -128,9 +129,13 @@ class Gamer:
                                      n_slots=concurrent_games or num_games)
 
     def _network(self):
+        """shared_storage.get() (Gamer.py:40,61).  A raw module / state dict is wrapped once and the wrapper kept, so
+        that its weights are only re-uploaded when they changed (Network_Manager.sync)."""
         nm = self.shared_storage.get() if hasattr(self.shared_storage, "get") else self.shared_storage
         if not isinstance(nm, Network_Manager):
-            nm = Network_Manager(nm)
+            if self._wrapped is None or self._wrapped[0] is not nm:
+                self._wrapped = (nm, Network_Manager(nm))
+            nm = self._wrapped[1]
         return nm
 
     def play_games(self):
@@ -138,7 +143,7 @@ class Gamer:
         if self.is_scs:
             return self._play_scs_games()
         nm = self._network() if self.shared_storage is not None else None
-        if nm is not None and self._loaded is not nm:
+        if nm is not None and self._loaded != (id(nm), nm.sync()):
             s = nm.spec()
             self.engine.set_weights(nm.state_dict(), width=s.width, num_blocks=s.num_blocks, recall=s.recall,
                                     value_activation=s.value_activation,
@@ -146,7 +151,7 @@ class Gamer:
                                     kernel_size=s.kernel_size)
             if self.cache_choice != "disabled":
                 self.engine.cache_all_positions()
-            self._loaded = nm
+            self._loaded = (id(nm), nm.version)
         self.engine.play(base_seed=self.base_seed)
         self.base_seed += self.num_games
         r = self.engine.export()
@@ -161,12 +166,12 @@ class Gamer:
     def _play_scs_games(self):
         from .scs import scs_game_records
         nm = self._network()
-        if self._loaded is not nm:
+        if self._loaded != (id(nm), nm.sync()):
             if self._board_net is not None:
                 self._board_net.close()
             c = self.scs_config
             self._board_net = nm.board_net(c.rows, c.cols, self.num_games, self.recurrent_iterations, self.device)
-            self._loaded = nm
+            self._loaded = (id(nm), nm.version)
         r = self.engine.play_native(self._board_net, range(self.base_seed, self.base_seed + self.num_games))
         self.base_seed += self.num_games
         records = scs_game_records(self.engine, r)

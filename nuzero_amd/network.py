@@ -55,17 +55,48 @@ class Network_Manager:
 
     def __init__(self, model, value_activation="tanh"):
         self.model = model
-        if isinstance(model, dict):
-            self._sd = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
-                        for k, v in model.items()}
-            self.recurrent = "projection.0.weight" in self._sd
-        else:
+        self._value_activation = value_activation
+        if not isinstance(model, dict):
             if not hasattr(model, "recurrent") or not isinstance(model.recurrent, bool):
                 raise Exception('You need to add a "recurrent" boolean attribute to the model')
-            self._sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-            self.recurrent = model.recurrent
-        self._spec = RecurrentNetSpec.from_state_dict(self._sd, value_activation)
+        self.version = 0            # bumped whenever the weights the engine should use have changed
+        self._stamp = None
         self._engine = None
+        self._engine_version = -1
+        self.refresh()
+
+    # ---- weight hand-off -------------------------------------------------------------------------
+    # The reference's trainer keeps ONE long-lived Network_Manager / module and trains it in place
+    # (Training/AlphaZero.py:152,293,462); Ray's get() handed every Gamer a fresh copy of it per game
+    # (Training/Gamer.py:37,61).  Without Ray the object's identity never changes, so the weights are
+    # re-read whenever the module's parameters were written to: every in-place write (optimizer step,
+    # load_state_dict) bumps torch's per-tensor version counter.
+    def _current_stamp(self):
+        if isinstance(self.model, dict):
+            return None
+        return tuple((id(t), t._version) for t in self.model.state_dict(keep_vars=True).values())
+
+    def refresh(self):
+        """Snapshot the model's weights now (always) and bump `version`."""
+        model = self.model
+        if isinstance(model, dict):
+            self._sd = {k: (v.detach().cpu().numpy().copy() if isinstance(v, torch.Tensor) else np.array(v))
+                        for k, v in model.items()}
+            self.recurrent = "projection.0.weight" in self._sd or "projection.0.kernel0" in self._sd
+        else:
+            self._sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+            self.recurrent = model.recurrent
+        self._stamp = self._current_stamp()
+        self._spec = RecurrentNetSpec.from_state_dict(self._sd, self._value_activation)
+        self.version += 1
+        return self.version
+
+    def sync(self):
+        """Re-read the weights if the module was trained / loaded since the last snapshot.  Returns `version`.
+        (dict models are plain data: call refresh() after editing one in place.)"""
+        if self._stamp is not None and self._current_stamp() != self._stamp:
+            self.refresh()
+        return self.version
 
     def is_recurrent(self):
         return self.recurrent
@@ -77,10 +108,18 @@ class Network_Manager:
         """The reference moves the module to cuda here (Network_Manager.py:41-44);
         the engine copies the weights itself, so nothing to do."""
 
+    def model_to_cpu(self):
+        """Network_Manager.py:32-33; the engine holds its own copy of the weights, nothing moves."""
+
+    def model_to_device(self):
+        """Network_Manager.py:35-36; see model_to_cpu."""
+
     def state_dict(self):
+        self.sync()
         return self._sd
 
     def spec(self):
+        self.sync()
         return self._spec
 
     def inference(self, state, training, iters_to_do=2, interim_thought=None):
@@ -88,15 +127,17 @@ class Network_Manager:
         kernel the search uses (Network_Manager.py:46-64, eval/no_grad branch)."""
         if training:
             raise NotImplementedError("the engine only evaluates; training stays in PyTorch")
+        version = self.sync()
         s = self._spec
         rows, cols = int(state.shape[-2]), int(state.shape[-1])
         if (s.in_channels, s.policy_channels, rows, cols, s.hex) != (2, 1, 3, 3, False):
             return self._board_inference(state, iters_to_do, rows, cols)
         from .engine import SelfPlayEngine
         from .search_config import legacy_ttt_search_config
-        if self._engine is None or self._engine.net_spec["iters"] != iters_to_do:
+        if self._engine is None or self._engine.net_spec["iters"] != iters_to_do or self._engine_version != version:
             if self._engine is None:
                 self._engine = SelfPlayEngine(legacy_ttt_search_config(), 16)
+            self._engine_version = version
             self._engine.set_weights(self._sd, width=s.width, num_blocks=s.num_blocks, recall=s.recall,
                                      value_activation=s.value_activation, recurrent_iterations=iters_to_do,
                                      arch=s.arch, kernel_size=s.kernel_size)
@@ -117,7 +158,7 @@ class Network_Manager:
 
     def _board_inference(self, state, iters_to_do, rows, cols):
         x = torch.as_tensor(state, dtype=torch.float32)
-        key = (rows, cols, iters_to_do, max(int(x.shape[0]), 16))
+        key = (rows, cols, iters_to_do, max(int(x.shape[0]), 16), self.sync())
         if getattr(self, "_board", None) is None or self._board[0] != key:
             if getattr(self, "_board", None) is not None:
                 self._board[1].close()

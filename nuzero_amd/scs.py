@@ -198,15 +198,18 @@ class ScsSelfPlay:
         self._check(lib.nz_scs_search_status(self._h, c_void_p(s.data_ptr()), self._stream()))
         return s.cpu().numpy()
 
-    def play(self, evaluator, seeds):
-        """Reset and play every game to the end; game g draws from RandomState(seeds[g]) in the
-        reference's order (gamma x n_root_children, two uniforms, at most one more for choice)."""
+    def play(self, evaluator, seeds, max_moves=None):
+        """Reset and play every game to the end (or for `max_moves` decisions); game g draws from
+        RandomState(seeds[g]) in the reference's order (gamma x n_root_children, two uniforms, at most one
+        more for choice).  `evaluator` may take a second argument: the game index of every leaf."""
         ex = self.search_config["Exploration"]
         G, A = self.n_games, self.cfg.num_actions
         rngs = [np.random.RandomState(int(s)) for s in seeds]
         self._check(lib.nz_scs_search_reset(self._h, self._stream()))
         nchild_dev = torch.empty((G,), dtype=torch.int32, device=self.device)
-        for _ in range(self.MAX_MOVES):
+        import inspect
+        wants_games = len(inspect.signature(evaluator).parameters) >= 2
+        for _ in range(min(self.MAX_MOVES, max_moves or self.MAX_MOVES)):
             st = self.status()
             alive = st[:, 4] == 0
             if not alive.any():
@@ -235,7 +238,10 @@ class ScsSelfPlay:
                                                      c_void_p(self._leaf_game.data_ptr()), byref(n), self._stream()))
                 if n.value == 0:
                     break
-                probs, values = evaluator(self._images[:n.value])
+                if wants_games:
+                    probs, values = evaluator(self._images[:n.value], self._leaf_game[:n.value])
+                else:
+                    probs, values = evaluator(self._images[:n.value])
                 probs = torch.as_tensor(probs, dtype=torch.float32).to(self.device).contiguous()
                 values = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous()
                 assert probs.shape == (n.value, A) and values.shape == (n.value,)
@@ -245,13 +251,14 @@ class ScsSelfPlay:
             self._check(lib.nz_scs_search_end_move(self._h, c_void_p(uni_d.data_ptr()), self._stream()))
         return self.export()
 
-    def play_native(self, net, seeds):
+    def play_native(self, net, seeds, max_moves=None):
         """As play(), with the network on the device as well (`net`: nuzero_amd.boardnet.BoardNet with
         max_batch >= n_games): the whole move loop runs in the library (nz_scs_search_play), the
         host only draws the per-move random numbers.  Same games as play(net.evaluator(), seeds)."""
         seeds = np.ascontiguousarray(np.asarray(list(seeds), dtype=np.uint32))
         assert seeds.shape == (self.n_games,)
-        self._check(lib.nz_scs_search_play(self._h, net._h, c_void_p(seeds.ctypes.data), self._stream()))
+        self._check(lib.nz_scs_search_play_moves(self._h, net._h, c_void_p(seeds.ctypes.data), int(max_moves or 0),
+                                                 self._stream()))
         out = self.export()
         self.evaluations = out["expansions"]
         waves = ctypes.c_int64(0)

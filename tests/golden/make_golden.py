@@ -266,6 +266,10 @@ NETS3 = {
     "H": ("resnet", 12, 105, 30, 6, 5, 48, 2, False, "relu", 1, 4, 2.0),
     "I": ("convnet", 13, 86, 21, 10, 10, 32, 3, False, "tanh", 1, 3, 2.0),
     "J": ("recurrent", 14, 86, 21, 5, 5, 64, 1, False, "relu", 3, 5, 2.0),
+    # BASELINE configs[4] network (Run.py:148, square form): 256 filters, 2 blocks, recall, relu value head,
+    # 16 recurrent iterations on a 10x10 board; configs[3] network (ConvNet_test.py:16, square form): 32 x 8
+    "K": ("recurrent", 15, 86, 21, 10, 10, 256, 2, True, "relu", 16, 3, 1.8),
+    "L": ("convnet", 16, 86, 21, 5, 5, 32, 8, False, "tanh", 1, 5, 2.0),
 }
 
 

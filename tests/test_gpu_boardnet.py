@@ -32,7 +32,7 @@ def _check(probs, value, logits, want_probs, want_value, want_logits):
     assert np.allclose(probs.sum(axis=1), 1.0, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+@pytest.mark.parametrize("name", ["G", "H", "I", "J", "K", "L"])
 def test_boardnet_equals_reference_outputs(net_kat3, name):
     import torch
     net, _ = _boardnet(name, 16)

@@ -492,3 +492,52 @@ def test_network_keeps_float32_range(net_kat, gain, value_tol):
     assert np.max(np.abs(logits.cpu().numpy() - p)) <= 1e-5 * scale
     np.testing.assert_allclose(value.cpu().numpy(), v.reshape(-1), rtol=0, atol=value_tol)
     eng.close()
+
+
+def test_gamer_and_inference_follow_in_place_weight_updates():
+    """Play a round, train the model in place (same module, same Network_Manager: what the reference's trainer hands
+    over after every step, AlphaZero.py:152,293,462), play again: the second round and Network_Manager.inference must use
+    the new weights -- identical to a fresh Gamer / Network_Manager built from them."""
+    import torch
+    from conftest import named_weights_module
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+
+    class tic_tac_toe:
+        pass
+
+    w0 = synthetic_recurrent_net_weights(1, 2, 1, 64, 2, True, 3.0)
+    w1 = synthetic_recurrent_net_weights(5, 2, 1, 64, 2, True, 3.0)
+    model = named_weights_module(w0)
+    nm = Network_Manager(model)
+    cfg = legacy_ttt_search_config(40)
+    keys = ("lengths", "outcomes", "actions", "visits", "child_prior", "child_value_sum")
+    x = _images([0, 1, 5, 14, 70, 7, 16, 86, 3, 9, 27, 81, 243, 4, 10, 28])
+
+    def round_of(gamer):
+        gamer.base_seed = 4
+        gamer.play_games()
+        return gamer.engine.export(trace=True)
+
+    g = Gamer(None, nm, tic_tac_toe, [], 0, cfg, 2, "disabled", num_games=32, base_seed=4)
+    r0 = round_of(g)
+    p0, v0 = nm.inference(x, False)
+    with torch.no_grad():
+        for p, v in zip(model.parameters(), w1.values()):
+            p.copy_(torch.from_numpy(v))
+    r1 = round_of(g)
+    p1, v1 = nm.inference(x, False)
+    fresh_nm = Network_Manager(w1)
+    fresh = Gamer(None, fresh_nm, tic_tac_toe, [], 0, cfg, 2, "disabled", num_games=32, base_seed=4)
+    r2 = round_of(fresh)
+    p2, v2 = fresh_nm.inference(x, False)
+    for k in keys:
+        assert np.array_equal(r1[k], r2[k]), k
+    assert any(not np.array_equal(r0[k], r1[k]) for k in keys)
+    assert torch.equal(p1, p2) and torch.equal(v1, v2) and not torch.equal(p0, p1)
+    r1b = round_of(g)                                   # unchanged weights: no re-upload, same games
+    for k in keys:
+        assert np.array_equal(r1[k], r1b[k]), k
+    g.engine.close(); fresh.engine.close()

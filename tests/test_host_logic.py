@@ -183,3 +183,36 @@ def test_game_record_contract():
     st = game_stats(r, 0)
     assert st == {"number_of_moves": 2, "average_children": 8.5, "average_tree_size": 113.0, "final_tree_size": 127,
                   "average_bias_value": (1.17 + 1.18) / 2, "final_bias_value": 1.18}
+
+
+def test_network_manager_follows_in_place_weight_updates():
+    """The reference's trainer trains one long-lived module in place and hands the same Network_Manager to the
+    Gamers after every step (Training/AlphaZero.py:152,293,462): the weights the engine uses must follow.
+    Host logic only (no GPU): the snapshot and its version."""
+    import torch
+    from conftest import named_weights_module
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    w0 = synthetic_recurrent_net_weights(1, 2, 1, 16, 2, True)
+    w1 = synthetic_recurrent_net_weights(2, 2, 1, 16, 2, True)
+    model = named_weights_module(w0)
+    nm = Network_Manager(model)
+    v0 = nm.sync()
+    assert nm.sync() == v0 and nm.is_recurrent()                  # nothing written: no new snapshot
+    assert all(np.array_equal(nm.state_dict()[k], w0[k]) for k in w0)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()                                                     # an optimizer step writes in place
+    assert nm.sync() == v0 + 1
+    assert all(np.array_equal(nm.state_dict()[k], w0[k] - 0.5) for k in w0)
+    with torch.no_grad():                                          # load_state_dict-style copy
+        for p, v in zip(model.parameters(), w1.values()):
+            p.copy_(torch.from_numpy(v))
+    assert nm.sync() == v0 + 2 and nm.sync() == v0 + 2
+    assert all(np.array_equal(nm.state_dict()[k], w1[k]) for k in w1)
+    d = Network_Manager(dict(w0))                                  # plain dicts are data: explicit refresh()
+    assert d.sync() == d.sync()
+    d.model["projection.0.weight"] = w1["projection.0.weight"]
+    assert d.refresh() == d.version and np.array_equal(d.state_dict()["projection.0.weight"], w1["projection.0.weight"])
+    nm.model_to_cpu(); nm.model_to_device(); nm.check_devices()   # surface of Network_Manager.py:32-44

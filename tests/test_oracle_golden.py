@@ -201,7 +201,7 @@ def test_feedforward_nets_against_reference(net_kat2, name):
         assert np.float32(v.reshape(-1)[0]) == net_kat2[f"{name}_value"][j]
 
 
-@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+@pytest.mark.parametrize("name", ["G", "H", "I", "J", "K", "L"])
 def test_board_sized_nets_against_reference(net_kat3, name):
     """The oracle nets on SCS-sized inputs (86/105 planes, 5x5 .. 10x10 boards, 21/30 policy planes)
     against the reference's RecurrentNet / ResNet / ConvNet (hex=False) through Network_Manager.inference
@@ -219,7 +219,7 @@ def test_board_sized_nets_against_reference(net_kat3, name):
         assert np.float32(v.reshape(-1)[0]) == kat[f"{name}_value"][i]
 
 
-@pytest.mark.parametrize("name", ["G", "H", "I", "J"])
+@pytest.mark.parametrize("name", ["G", "H", "I", "J", "K", "L"])
 def test_hex_nets_against_reference(name):
     """Pins oracle/net.py HexNetRef to the reference's hex=True nets -- once tests/golden/net_kat_hex.npz exists
     (tests/golden/make_golden_hex.py needs the real hexagdly package, which the build container lacks: until
