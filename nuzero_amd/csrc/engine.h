@@ -23,14 +23,22 @@ __host__ __device__ inline uint32_t meta_children(uint32_t m) { return m & 0xfff
 __host__ __device__ inline uint32_t meta_action(uint32_t m) { return (m >> 12) & 0xfffu; }
 __host__ __device__ inline uint32_t meta_to_play(uint32_t m) { return (m >> 24) & 0xfu; }
 
+// One tree node (Search/Node.py:3-32), 48 bytes = three 16-byte loads; a node's children are
+// contiguous and in ascending action order.
+struct __attribute__((aligned(16))) TNode {
+  double value_sum;
+  double q;               // value_sum / visit, 0.0 while unvisited (Node.value()); rewritten by every backup
+  double prior;
+  int32_t visit;
+  uint32_t first;         // index of the first child
+  uint32_t meta;          // packed: see pack_meta
+  uint32_t pad[3];
+};
+static_assert(sizeof(TNode) == 48, "three 16-byte loads per node");
+
 // Everything the tree kernels need, passed by value.
 struct TreeParams {
-  // structure-of-arrays node storage, [G][cap]; a node's children are
-  // contiguous and in ascending action order
-  int32_t* visit;
-  double* value_sum;
-  double* prior;
-  uint2* link;            // x = index of first child, y = packed meta
+  TNode* nodes;           // [n_slots][cap]
   int32_t cap;
   int32_t n_games;        // games per self-play round (records, random tables)
   int32_t n_slots;        // games in flight at once (tree arenas); lock-step needs n_slots == n_games

@@ -305,7 +305,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   const size_t G = n_games, N = (size_t)n_slots * (size_t)e->cap, GT = G * TTT_MAX_MOVES, GTA = GT * TTT_ACTIONS;
 #define A(ptr, n)                                        \
   if ((st = dev_alloc(e, &(ptr), (n))) != NZ_OK) return bail(st)
-  A(p.visit, N); A(p.value_sum, N); A(p.prior, N); A(p.link, N);
+  A(p.nodes, N);
   A(p.board, G); A(p.length, G); A(p.alive, G); A(p.outcome, G); A(p.root, G); A(p.node_count, G);
   A(p.sims_left, G); A(p.pending, G); A(p.leaf_board, G); A(p.path, G * MAX_PATH); A(p.path_len, G);
   A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.desync, G); A(p.n_root_children, G);

@@ -343,6 +343,11 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
       epilogue_lds<OMASK, 0, false>(acc, dst, nullptr, lane, job.nt);
     }
   } else if (job.dst == NET_DST_POLICY) {     // policy logits [pos][P][9]
+    // (addresses re-derived from an opaque copy of the lane id: hoisted out of the job loop they would sit in
+    // registers -- in the persistent kernel: in scratch memory -- for the whole network)
+    int l2 = lane;
+    asm volatile("" : "+v"(l2));
+    const int pos = l2 & 15, quad = l2 >> 4;
     if (pos < n_valid) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

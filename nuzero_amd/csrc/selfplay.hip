@@ -35,41 +35,111 @@
 namespace nz {
 namespace {
 
+// Tree-phase state of one row (game slot); see `park` below.
+struct RowState {
+  bool alive = false, pending = false;
+  int g = 0, root = 0, node_count = 1, sims_left = 0, move = 0;
+  uint32_t board = 0u;
+  int n_sim = 0, n_exp = 0, n_lvl = 0, n_kid = 0;
+  int path_len = 0, leaf = 0, win0 = -1;
+  uint32_t leaf_sb = 0u, leaf_meta = 0u;
+  int outcome = 0;
+  int my_node = 0, my_n = 0;      // per lane: path node i of the parked simulation
+  double my_vs = 0.0;
+};
+constexpr int PARK_ROW_WORDS = 23, PARK_LANE_WORDS = 13;
+__device__ __forceinline__ void park(const RowState& s, const RootCache& rc, int32_t (*row)[POS],
+                                     int32_t (*lane)[NET_THREADS], int slot, int sub, int tid) {
+  if (sub == 0) {
+    row[0][slot] = (s.alive ? 1 : 0) | (s.pending ? 2 : 0);
+    row[1][slot] = s.g; row[2][slot] = s.root; row[3][slot] = s.node_count; row[4][slot] = s.sims_left;
+    row[5][slot] = s.move; row[6][slot] = (int32_t)s.board; row[7][slot] = s.n_sim; row[8][slot] = s.n_exp;
+    row[9][slot] = s.n_lvl; row[10][slot] = s.n_kid; row[11][slot] = s.path_len; row[12][slot] = s.leaf;
+    row[13][slot] = s.win0; row[14][slot] = (int32_t)s.leaf_sb; row[15][slot] = (int32_t)s.leaf_meta;
+    row[16][slot] = s.outcome; row[17][slot] = rc.k; row[18][slot] = rc.base; row[19][slot] = rc.root_n;
+    row[20][slot] = __double2loint(rc.root_vs); row[21][slot] = __double2hiint(rc.root_vs);
+    row[22][slot] = (int32_t)rc.root_meta;
+  }
+  lane[0][tid] = s.my_node; lane[1][tid] = s.my_n;
+  lane[2][tid] = __double2loint(s.my_vs); lane[3][tid] = __double2hiint(s.my_vs);
+  lane[4][tid] = rc.n;
+  lane[5][tid] = __double2loint(rc.vs); lane[6][tid] = __double2hiint(rc.vs);
+  lane[7][tid] = __double2loint(rc.q); lane[8][tid] = __double2hiint(rc.q);
+  lane[9][tid] = __double2loint(rc.pr); lane[10][tid] = __double2hiint(rc.pr);
+  lane[11][tid] = (int32_t)rc.lk.x; lane[12][tid] = (int32_t)rc.lk.y;
+}
+__device__ __forceinline__ void unpark(RowState& s, RootCache& rc, int32_t (*row)[POS], int32_t (*lane)[NET_THREADS],
+                                       int slot, int sub, int tid) {
+  const int f = row[0][slot];
+  s.alive = (f & 1) != 0; s.pending = (f & 2) != 0;
+  s.g = row[1][slot]; s.root = row[2][slot]; s.node_count = row[3][slot]; s.sims_left = row[4][slot];
+  s.move = row[5][slot]; s.board = (uint32_t)row[6][slot]; s.n_sim = row[7][slot]; s.n_exp = row[8][slot];
+  s.n_lvl = row[9][slot]; s.n_kid = row[10][slot]; s.path_len = row[11][slot]; s.leaf = row[12][slot];
+  s.win0 = row[13][slot]; s.leaf_sb = (uint32_t)row[14][slot]; s.leaf_meta = (uint32_t)row[15][slot];
+  s.outcome = row[16][slot]; rc.k = row[17][slot]; rc.base = row[18][slot]; rc.root_n = row[19][slot];
+  rc.root_vs = __hiloint2double(row[21][slot], row[20][slot]);
+  rc.root_meta = (uint32_t)row[22][slot];
+  s.my_node = lane[0][tid]; s.my_n = lane[1][tid];
+  s.my_vs = __hiloint2double(lane[3][tid], lane[2][tid]);
+  rc.n = lane[4][tid];
+  rc.vs = __hiloint2double(lane[6][tid], lane[5][tid]);
+  rc.q = __hiloint2double(lane[8][tid], lane[7][tid]);
+  rc.pr = __hiloint2double(lane[10][tid], lane[9][tid]);
+  rc.lk = make_uint2((uint32_t)lane[11][tid], (uint32_t)lane[12][tid]);
+  (void)sub;
+}
+
 // STAMPS = true is the diagnostic build: thread 0 of every workgroup adds up the
 // shader-clock ticks it spends in each phase ([block][4] = cycles of the loop,
 // tree ticks, net ticks, total ticks).  The product build carries no stamp.
+struct SelfplayArgs {
+  TreeParams p;
+  const NetProgram* prog;
+  const float* W;
+  const double* noise;        // [G][T][A]
+  const double* uniforms;     // [G][T][3]
+  unsigned long long* stamps;
+};
+// The kernel's arguments live in the kernarg segment (constant memory).  Each phase reads what it needs from there
+// through a pointer the compiler cannot see through, instead of holding ~110 scalar registers of pointers (and
+// per-lane addresses derived from them) alive across the network phase, where they would be spilled.
+__device__ __forceinline__ const SelfplayArgs& kernel_args() {
+  auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));
+  return *(const SelfplayArgs*)(const void*)kp;
+}
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 template <bool STAMPS>
-__global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, const NetProgram* __restrict__ prog,
-                                                               int n_layers, const float* __restrict__ W,
-                                                               const double* __restrict__ noise,      // [G][T][A]
-                                                               const double* __restrict__ uniforms,   // [G][T][3]
-                                                               unsigned long long* __restrict__ stamps) {
+__global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   __shared__ __attribute__((aligned(16))) float lds[NET_LDS_FLOATS + POS * TTT_ACTIONS + POS];
   float* const inp = lds + NET_BUFFERS * ACT_FLOATS;
   float* const out_logits = inp + INP_FLOATS;          // [16][9]
   float* const out_value = out_logits + POS * TTT_ACTIONS;
 
-  const int tid = threadIdx.x;
   // K groups may reach past a narrow layer's channels (their weights are zero): no NaN bit patterns in LDS
-  for (int idx = tid; idx < NET_BUFFERS * ACT_FLOATS; idx += NET_THREADS) lds[idx] = 0.0f;
-  const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
-  const int sub = tid & (LANES_PER_GAME - 1);
-  const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
-  int g = gslot;                                       // game being played in this slot
+  for (int idx = threadIdx.x; idx < NET_BUFFERS * ACT_FLOATS; idx += NET_THREADS) lds[idx] = 0.0f;
 
-  // per-game state, identical on the 16 lanes of a row (except my_node)
-  bool alive = gslot < p.n_slots && g < p.n_games;
-  const Arena t = arena_of(p, gslot < p.n_slots ? gslot : 0);
-  int root = 0, node_count = 1, sims_left = p.sims, move = 0;
-  uint32_t board = 0u;
-  int n_sim = 0, n_exp = 0, n_lvl = 0, n_kid = 0;
-  bool pending = false;
-  int my_node = 0, path_len = 0, leaf = 0, my_n = 0, win0 = -1;
-  double my_vs = 0.0;
-  uint32_t leaf_sb = 0u, leaf_meta = 0u;
-  RootCache rc;
-  root_cache_load(rc, t, 0, sub);
-  int outcome = 0;
+  // The network phase needs the whole register file (256 + 256 per lane); the tree phase's state waits in LDS
+  // meanwhile -- one word per game for what the 16 lanes of a row share, one per lane for the rest -- and lives in
+  // registers only between `unpark` and `park`, so nothing is spilled to scratch memory around net_tile.
+  __shared__ int32_t park_row[PARK_ROW_WORDS][POS];
+  __shared__ int32_t park_lane[PARK_LANE_WORDS][NET_THREADS];
+  {
+    const TreeParams& p = kernel_args().p;
+    const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
+    const int gslot = blockIdx.x * POS + slot;
+    RootCache rc0;
+    root_cache_load(rc0, arena_of(p, gslot < p.n_slots ? gslot : 0), 0, sub);
+    RowState st0;
+    st0.alive = gslot < p.n_slots && gslot < p.n_games;
+    st0.g = gslot;                                     // game being played in this slot
+    st0.sims_left = p.sims;
+    park(st0, rc0, park_row, park_lane, slot, sub, tid);
+  }
   unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0;
   if constexpr (STAMPS) t_begin = t0 = __builtin_amdgcn_s_memtime();
 
@@ -78,11 +148,34 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
   int cycle = 0;
   for (;;) {
     // ------------------------------ tree phase ---------------------------------
+    // (per-lane indices and the arguments are re-derived here every cycle: loop-invariant values would be kept in
+    // registers across the network phase)
+    const int tid = opaque(threadIdx.x);
+    const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
+    const int sub = tid & (LANES_PER_GAME - 1);
+    const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
+    const SelfplayArgs& ka = kernel_args();
+    const TreeParams& p = ka.p;
+    const double* const noise = ka.noise;
+    const double* const uniforms = ka.uniforms;
     int cyc_sims = 0;
     if constexpr (STAMPS) {
       if (tid == 0) s_max_sims = 0;
       __syncthreads();
     }
+    RowState st;
+    RootCache rc;
+    unpark(st, rc, park_row, park_lane, slot, sub, tid);
+    const Arena t = arena_of(p, gslot < p.n_slots ? gslot : 0);
+    bool& alive = st.alive;
+    bool& pending = st.pending;
+    int &g = st.g, &root = st.root, &node_count = st.node_count, &sims_left = st.sims_left, &move = st.move;
+    uint32_t& board = st.board;
+    int &n_sim = st.n_sim, &n_exp = st.n_exp, &n_lvl = st.n_lvl, &n_kid = st.n_kid;
+    int &my_node = st.my_node, &path_len = st.path_len, &leaf = st.leaf, &my_n = st.my_n, &win0 = st.win0;
+    double& my_vs = st.my_vs;
+    uint32_t &leaf_sb = st.leaf_sb, &leaf_meta = st.leaf_meta;
+    int& outcome = st.outcome;
     if (alive) {
       if (pending) {
         const float logit = sub < 9 ? out_logits[slot * TTT_ACTIONS + sub] : 0.0f;
@@ -167,7 +260,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
         const int term = ttt_terminal(d.sb);
         if (term != 0) {
           if (sub == 0)
-            t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
+            t[d.node].meta = pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term);
           backup_cached(t, rc, my_node, my_n, my_vs, d.path_len, (double)term_value(term), sub, win0);
           row_memory_fence();
           --sims_left;
@@ -209,6 +302,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
     if constexpr (STAMPS) {
       if (sub == 0) atomicMax(&s_max_sims, cyc_sims);
     }
+    park(st, rc, park_row, park_lane, slot, sub, tid);
     const int any_alive = __syncthreads_or(alive ? 1 : 0);
     const int any_pending = __syncthreads_or(pending ? 1 : 0);
     if constexpr (STAMPS) {
@@ -225,7 +319,10 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
     if (!any_pending) continue;       // every live row used up its simulations for this cycle
 
     // ------------------------------ net phase ----------------------------------
-    net_tile(prog, W, lds, inp, 1, POS, out_logits, out_value);
+    {
+      const SelfplayArgs& na = kernel_args();
+      net_tile(na.prog, na.W, lds, inp, 1, POS, out_logits, out_value);
+    }
     // net_tile ends with a barrier: outputs are visible to every row
     if constexpr (STAMPS) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -234,6 +331,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(TreeParams p, con
       ++n_cycles;
     }
   }
+  const SelfplayArgs& ea = kernel_args();
+  const TreeParams& p = ea.p;
+  unsigned long long* const stamps = ea.stamps;
+  const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
+  const int gslot = blockIdx.x * POS + slot;
   if constexpr (STAMPS) {
     if (tid == 0) {
       stamps[blockIdx.x * 4 + 0] = n_cycles;
@@ -262,12 +364,10 @@ int selfplay_blocks(int n_slots) { return (n_slots + POS - 1) / POS; }
 void launch_selfplay(const TreeParams& p, const NetProgram* prog_dev, int n_layers, const float* weights,
                      const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s) {
   const int blocks = selfplay_blocks(p.n_slots);
-  if (stamps != nullptr)
-    hipLaunchKernelGGL(selfplay_kernel<true>, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights,
-                       noise, uniforms, stamps);
-  else
-    hipLaunchKernelGGL(selfplay_kernel<false>, dim3(blocks), dim3(NET_THREADS), 0, s, p, prog_dev, n_layers, weights,
-                       noise, uniforms, stamps);
+  (void)n_layers;
+  const SelfplayArgs a{p, prog_dev, weights, noise, uniforms, stamps};
+  if (stamps != nullptr) hipLaunchKernelGGL(selfplay_kernel<true>, dim3(blocks), dim3(NET_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(selfplay_kernel<false>, dim3(blocks), dim3(NET_THREADS), 0, s, a);
 }
 
 }  // namespace nz

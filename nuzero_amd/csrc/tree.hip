@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
       const float logit = sub < 9 ? p.leaf_logits[(size_t)pend * TTT_ACTIONS + sub] : 0.0f;
       const float prob = row_softmax9(logit, sub);
       const double value = (double)p.leaf_value[pend];
-      node_count = expand_row(p, t, leaf, t.link[leaf].y, sb, prob, sub, node_count);
+      node_count = expand_row(p, t, leaf, t[leaf].meta, sb, prob, sub, node_count);
       backup_row(t, my_node, path_len, value, sub);
       row_memory_fence();
       --sims_left;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
       const int term = ttt_terminal(d.sb);
       if (term != 0) {
         if (sub == 0)
-          t.link[d.node] = make_uint2(0u, pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term));
+          t[d.node].meta = pack_meta(0u, meta_action(d.lk.y), (uint32_t)ttt_player(d.sb), (uint32_t)term);
         backup_row(t, my_node, d.path_len, (double)term_value(term), sub);
         row_memory_fence();
         --sims_left;

@@ -19,9 +19,13 @@
 // the same leaf evaluations the visit counts are bit-identical to the
 // reference's.
 //
-// Storage: structure-of-arrays per game arena; a node's children are contiguous
-// in ascending action order, so lane j of the row reads child j with one
-// coalesced access per array.
+// Storage: one 48-byte record per node (engine.h TNode), a node's children contiguous in
+// ascending action order, so lane j of the row reads child j as three 16-byte loads from
+// consecutive addresses (k children = k * 48 contiguous bytes: 4 cache lines for 9).  A record
+// carries Q = value_sum / visit_count (Node.value(), Search/Node.py:19-22) beside the two:
+// Q changes for exactly one child per level per simulation -- the one backed up -- so the
+// backup rewrites it (one division per path node, lane-parallel) and select reads it, instead
+// of every level dividing for every child.  Same operands, same IEEE division: same double.
 #pragma once
 #include "engine.h"
 
@@ -96,26 +100,20 @@ __device__ __forceinline__ float row_softmax9(float logit, int sub) {
 // compiler keeps the order.
 __device__ __forceinline__ void row_memory_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
 
-struct Arena {
-  int32_t* visit;
-  double* value_sum;
-  double* prior;
-  uint2* link;
-};
-__device__ __forceinline__ Arena arena_of(const TreeParams& p, int g) {
-  const size_t off = (size_t)g * (size_t)p.cap;
-  return Arena{p.visit + off, p.value_sum + off, p.prior + off, p.link + off};
+typedef TNode* Arena;
+__device__ __forceinline__ Arena arena_of(const TreeParams& p, int g) { return p.nodes + (size_t)g * (size_t)p.cap; }
+__device__ __forceinline__ TNode fresh_node(uint32_t action) {
+  TNode n;
+  n.value_sum = 0.0; n.q = 0.0; n.prior = 0.0; n.visit = 0; n.first = 0u;
+  n.meta = pack_meta(0u, action, TO_PLAY_UNSET, 0u);
+  n.pad[0] = n.pad[1] = n.pad[2] = 0u;
+  return n;
 }
-__device__ __forceinline__ void arena_reset(const Arena& t) {   // Node(0), Gamer.py:59
-  t.visit[0] = 0;
-  t.value_sum[0] = 0.0;
-  t.prior[0] = 0.0;
-  t.link[0] = make_uint2(0u, pack_meta(0u, 0u, TO_PLAY_UNSET, 0u));
-}
+__device__ __forceinline__ void arena_reset(Arena t) { t[0] = fresh_node(0u); }   // Node(0), Gamer.py:59
 
 // Explorer.evaluate's expansion (Explorer.py:165-179).  `prob` is this lane's
 // post-softmax float32 probability for action `sub`.  Returns the new node count.
-__device__ __forceinline__ int expand_row(const TreeParams& p, const Arena& t, int leaf, uint32_t leaf_meta,
+__device__ __forceinline__ int expand_row(const TreeParams& p, Arena t, int leaf, uint32_t leaf_meta,
                                           uint32_t sb, float prob, int sub, int node_count) {
   const uint32_t empty = ttt_empty(sb);
   const bool legal = sub < 9 && ((empty >> sub) & 1u);
@@ -134,28 +132,40 @@ __device__ __forceinline__ int expand_row(const TreeParams& p, const Arena& t, i
   }
   if (legal) {
     const int c = base + __popc(empty & ((1u << sub) - 1u));
-    t.visit[c] = 0;
-    t.value_sum[c] = 0.0;
-    t.prior[c] = pd / total;
-    t.link[c] = make_uint2(0u, pack_meta(0u, (uint32_t)sub, TO_PLAY_UNSET, 0u));
+    TNode n = fresh_node((uint32_t)sub);
+    n.prior = pd / total;
+    t[c] = n;
   }
-  if (sub == 0)
-    t.link[leaf] = make_uint2((uint32_t)base,
-                              pack_meta((uint32_t)k, meta_action(leaf_meta), (uint32_t)ttt_player(sb), 0u));
+  if (sub == 0) {
+    t[leaf].first = (uint32_t)base;
+    t[leaf].meta = pack_meta((uint32_t)k, meta_action(leaf_meta), (uint32_t)ttt_player(sb), 0u);
+  }
   return node_count + k;
 }
 
 // Explorer.backpropagate (Explorer.py:132-135): lane i owns path node i.
-__device__ __forceinline__ void backup_row(const Arena& t, int my_node, int path_len, double value, int sub) {
+__device__ __forceinline__ void backup_row(Arena t, int my_node, int path_len, double value, int sub) {
   if (sub < path_len) {
-    t.visit[my_node] += 1;
-    t.value_sum[my_node] = t.value_sum[my_node] + value;
+    const int n = t[my_node].visit + 1;
+    const double vs = t[my_node].value_sum + value;
+    t[my_node].visit = n;
+    t[my_node].value_sum = vs;
+    t[my_node].q = vs / (double)n;
   }
 }
 
-// One descent from `root` (Explorer.py:51-58).  On return `node`/`lk` is the
-// leaf and its link word, `sb` the scratch position there, `path_len` the
-// number of nodes on the path and lane i's `my_node` is path node i.
+// PUCT score of one child (Explorer.py:103-130), shared by both descents.  `q` is the child's stored
+// value_sum / visit_count (0.0 while unvisited, Node.py:19-22).
+__device__ __forceinline__ double puct_score(const TreeParams& p, double sq, double cb, bool negate, int n, double q,
+                                             double pr) {
+  const double u = sq / (double)(n + 1);
+  double conf = pr * u;
+  conf = conf * cb;
+  if (negate) q = -q;
+  q = q * p.value_factor;
+  return conf + q;
+}
+
 // rotate a value by N lanes inside its 16-lane row (DPP row_ror: no LDS round trip)
 template <int N>
 __device__ __forceinline__ int row_ror(int v) {
@@ -186,7 +196,7 @@ struct Descent {
   int path_len;
   int levels, children;   // work done, for the byte accounting
 };
-__device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena& t, int root, uint32_t board,
+__device__ __forceinline__ Descent descend_row(const TreeParams& p, Arena t, int root, uint32_t board,
                                                int sub, int& my_node) {
   Descent d;
   d.node = root;
@@ -195,8 +205,8 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
   d.levels = 0;
   d.children = 0;
   if (sub == 0) my_node = root;
-  d.lk = t.link[root];
-  int n_parent = t.visit[root];     // below the root it is carried down from the chosen child
+  d.lk = make_uint2(t[root].first, t[root].meta);
+  int n_parent = t[root].visit;     // below the root it is carried down from the chosen child
   while (meta_children(d.lk.y) != 0u) {
     const int k = (int)meta_children(d.lk.y);
     const int base = (int)d.lk.x;
@@ -214,18 +224,10 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, const Arena&
     int n = 0;
     uint2 clk = make_uint2(0u, 0u);
     if (sub < k) {
-      const int child = base + sub;
-      n = t.visit[child];
-      const double vs = t.value_sum[child];
-      const double pr = t.prior[child];
-      clk = t.link[child];
-      const double u = sq / (double)(n + 1);
-      double conf = pr * u;
-      conf = conf * cb;
-      double q = (n == 0) ? 0.0 : vs / (double)n;
-      if (negate) q = -q;
-      q = q * p.value_factor;
-      score = conf + q;
+      const TNode c = t[base + sub];
+      n = c.visit;
+      clk = make_uint2(c.first, c.meta);
+      score = puct_score(p, sq, cb, negate, n, c.q, c.prior);
       key = ((int)meta_action(clk.y) << 8) | sub;
     }
     // max over (score, action): the larger action wins a tie (Explorer.py:100)
@@ -260,42 +262,33 @@ struct RootCache {
   double root_vs;
   uint32_t root_meta;
   int n;                 // lane j < k: child j
-  double vs, pr;
+  double vs, q, pr;
   uint2 lk;
 };
-__device__ __forceinline__ void root_cache_load(RootCache& c, const Arena& t, int root, int sub) {
-  const uint2 lk = t.link[root];
-  c.k = (int)meta_children(lk.y);
-  c.base = (int)lk.x;
-  c.root_meta = lk.y;
-  c.root_n = t.visit[root];
-  c.root_vs = t.value_sum[root];
+__device__ __forceinline__ void root_cache_load(RootCache& c, Arena t, int root, int sub) {
+  const TNode r = t[root];
+  c.k = (int)meta_children(r.meta);
+  c.base = (int)r.first;
+  c.root_meta = r.meta;
+  c.root_n = r.visit;
+  c.root_vs = r.value_sum;
   c.n = 0;
   c.vs = 0.0;
+  c.q = 0.0;
   c.pr = 0.0;
   c.lk = make_uint2(0u, 0u);
   if (sub < c.k) {
-    const int child = c.base + sub;
-    c.n = t.visit[child];
-    c.vs = t.value_sum[child];
-    c.pr = t.prior[child];
-    c.lk = t.link[child];
+    const TNode ch = t[c.base + sub];
+    c.n = ch.visit;
+    c.vs = ch.value_sum;
+    c.q = ch.q;
+    c.pr = ch.prior;
+    c.lk = make_uint2(ch.first, ch.meta);
   }
-}
-// PUCT score of one child (Explorer.py:103-130), shared by both descents
-__device__ __forceinline__ double puct_score(const TreeParams& p, double sq, double cb, bool negate, int n, double vs,
-                                             double pr) {
-  const double u = sq / (double)(n + 1);
-  double conf = pr * u;
-  conf = conf * cb;
-  double q = (n == 0) ? 0.0 : vs / (double)n;
-  if (negate) q = -q;
-  q = q * p.value_factor;
-  return conf + q;
 }
 // As descend_row; additionally lane i receives path node i's (visit, value_sum) as read
 // during the descent (my_n, my_vs) and win0 is the lane of the chosen root child (-1: none).
-__device__ __forceinline__ Descent descend_cached(const TreeParams& p, const Arena& t, const RootCache& c, int root,
+__device__ __forceinline__ Descent descend_cached(const TreeParams& p, Arena t, const RootCache& c, int root,
                                                   uint32_t board, int sub, int& my_node, int& my_n, double& my_vs,
                                                   int& win0) {
   Descent d;
@@ -330,17 +323,15 @@ __device__ __forceinline__ Descent descend_cached(const TreeParams& p, const Are
     double vs = 0.0;
     uint2 clk = make_uint2(0u, 0u);
     if (sub < k) {
-      double pr;
+      double pr, q;
       if (d.path_len == 1) {          // children of the root: registers
-        n = c.n; vs = c.vs; pr = c.pr; clk = c.lk;
+        n = c.n; vs = c.vs; q = c.q; pr = c.pr; clk = c.lk;
       } else {
-        const int child = base + sub;
-        n = t.visit[child];
-        vs = t.value_sum[child];
-        pr = t.prior[child];
-        clk = t.link[child];
+        const TNode ch = t[base + sub];
+        n = ch.visit; vs = ch.value_sum; q = ch.q; pr = ch.prior;
+        clk = make_uint2(ch.first, ch.meta);
       }
-      score = puct_score(p, sq, cb, negate, n, vs, pr);
+      score = puct_score(p, sq, cb, negate, n, q, pr);
       key = ((int)meta_action(clk.y) << 8) | sub;
     }
     argmax_step<8>(score, key);
@@ -366,30 +357,32 @@ __device__ __forceinline__ Descent descend_cached(const TreeParams& p, const Are
   return d;
 }
 // Explorer.backpropagate without loads: lane i stores path node i from the values the descent read
-__device__ __forceinline__ void backup_cached(const Arena& t, RootCache& c, int my_node, int my_n, double my_vs,
+__device__ __forceinline__ void backup_cached(Arena t, RootCache& c, int my_node, int my_n, double my_vs,
                                               int path_len, double value, int sub, int win0) {
   if (sub < path_len) {
-    t.visit[my_node] = my_n + 1;
-    t.value_sum[my_node] = my_vs + value;
+    const double vs = my_vs + value;
+    t[my_node].visit = my_n + 1;
+    t[my_node].value_sum = vs;
+    t[my_node].q = vs / (double)(my_n + 1);
   }
   c.root_n += 1;
   c.root_vs = c.root_vs + value;
   if (path_len >= 2 && sub == win0) {
     c.n += 1;
     c.vs = c.vs + value;
+    c.q = c.vs / (double)c.n;
   }
 }
 
 // Root noise (Explorer.py:201-210): lane j mixes child j's prior.
-__device__ __forceinline__ void noise_row(const TreeParams& p, const Arena& t, int root, const double* noise_row9,
+__device__ __forceinline__ void noise_row(const TreeParams& p, Arena t, int root, const double* noise_row9,
                                           int sub) {
-  const uint2 lk = t.link[root];
-  const int k = (int)meta_children(lk.y);
+  const int k = (int)meta_children(t[root].meta);
   if (sub < k) {
-    const int c = (int)lk.x + sub;
-    const double a = t.prior[c] * p.one_minus_frac;
+    const int c = (int)t[root].first + sub;
+    const double a = t[c].prior * p.one_minus_frac;
     const double b = noise_row9[sub] * p.frac;
-    t.prior[c] = a + b;
+    t[c].prior = a + b;
   }
 }
 
@@ -431,12 +424,11 @@ struct MoveResult {
 // (Gamer.py:78-79).  `record` is the game's row in the hist_* arrays.
 // `forced` >= 0 plays that action instead of the search's own choice (the opponent's move in
 // MctsAgent.update_subtree, Testing/Agents/Generic/MctsAgent.py:35-39).
-__device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t, int record, int root,
+__device__ inline MoveResult finish_move_one(const TreeParams& p, Arena t, int record, int root,
                                              uint32_t board, int move, const double* uni3, int forced = -1) {
   MoveResult r{-1, root, board, 0, 0};
-  const uint2 lk = t.link[root];
-  const int k = (int)meta_children(lk.y);
-  const int base = (int)lk.x;
+  const int k = (int)meta_children(t[root].meta);
+  const int base = (int)t[root].first;
   const int gm = record * TTT_MAX_MOVES + move;
   if (k == 0) {
     atomicOr(p.error_flag, 4);      // search did not complete
@@ -444,19 +436,19 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t
   }
   int counts[TTT_ACTIONS], actions[TTT_ACTIONS];
   for (int j = 0; j < k; ++j) {
-    const int c = base + j;
-    counts[j] = t.visit[c];
-    actions[j] = (int)meta_action(t.link[c].y);
+    const TNode c = t[base + j];
+    counts[j] = c.visit;
+    actions[j] = (int)meta_action(c.meta);
     p.hist_visits[gm * TTT_ACTIONS + actions[j]] = counts[j];
-    p.hist_prior[gm * TTT_ACTIONS + actions[j]] = t.prior[c];
-    p.hist_value_sum[gm * TTT_ACTIONS + actions[j]] = t.value_sum[c];
+    p.hist_prior[gm * TTT_ACTIONS + actions[j]] = c.prior;
+    p.hist_value_sum[gm * TTT_ACTIONS + actions[j]] = c.value_sum;
   }
-  const int root_visits = t.visit[root];
+  const int root_visits = t[root].visit;
   p.hist_board[gm] = board;
   p.hist_tree_size[gm] = root_visits;
   p.hist_children[gm] = k;
   p.hist_bias[gm] = root_visits < p.tab_len ? p.bias_tab[root_visits] : 0.0;
-  p.hist_root_value_sum[gm] = t.value_sum[root];
+  p.hist_root_value_sum[gm] = t[root].value_sum;
 
   int mode = 0;       // 0 max, 1 softmax over visit counts, 2 uniform over legal, 3 forced
   double u3 = 0.0;
@@ -508,7 +500,7 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, const Arena& t
   for (int j = 0; j < k; ++j)
     if (actions[j] == chosen) r.new_root = base + j;
   r.term = ttt_terminal(r.new_board);
-  r.new_children = (int)meta_children(t.link[r.new_root].y);
+  r.new_children = (int)meta_children(t[r.new_root].meta);
   return r;
 }
 
