@@ -35,6 +35,21 @@
 namespace nz {
 namespace {
 
+// The register copy of the root's children after an expansion: the root itself got children (path of one node) ->
+// load them; a child of the root got children (path of two) -> only its link word changed, and the lane that holds it
+// knows the new one (what expand_row wrote); deeper expansions do not touch the copy.
+__device__ __forceinline__ void expanded_near_root(RootCache& rc, Arena t, int root, int sub, int path_len, int win0,
+                                                   int base0, int node_count, uint32_t leaf_meta, uint32_t leaf_sb) {
+  if (path_len == 1) {
+    root_cache_load(rc, t, root, sub);
+  } else if (path_len == 2 && sub == win0 && node_count > base0) {
+    rc.lk = make_uint2((uint32_t)base0, pack_meta((uint32_t)(node_count - base0), meta_action(leaf_meta),
+                                                  (uint32_t)ttt_player(leaf_sb), 0u));
+  }
+}
+
+constexpr int LDS_TAB = 960;     // entries of the (sqrt, bias) tables kept in LDS: enough for 100 simulations per move
+
 // Tree-phase state of one row (game slot); see `park` below.
 struct RowState {
   bool alive = false, pending = false;
@@ -128,8 +143,12 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   // registers only between `unpark` and `park`, so nothing is spilled to scratch memory around net_tile.
   __shared__ int32_t park_row[PARK_ROW_WORDS][POS];
   __shared__ int32_t park_lane[PARK_LANE_WORDS][NET_THREADS];
+  // sqrt(N) and log((N + base + 1) / base) + init of the parent count (Explorer.py:103-112), first LDS_TAB entries:
+  // the root's children are scored from registers, with these here a descent's first level touches no memory at all
+  __shared__ double2 tab[LDS_TAB];
   {
     const TreeParams& p = kernel_args().p;
+    for (int i = threadIdx.x; i < LDS_TAB && i < p.tab_len; i += NET_THREADS) tab[i] = make_double2(p.sqrt_tab[i], p.bias_tab[i]);
     const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
     const int gslot = blockIdx.x * POS + slot;
     RootCache rc0;
@@ -158,6 +177,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     const TreeParams& p = ka.p;
     const double* const noise = ka.noise;
     const double* const uniforms = ka.uniforms;
+    const int tab_n = p.tab_len < LDS_TAB ? p.tab_len : LDS_TAB;
     int cyc_sims = 0;
     if constexpr (STAMPS) {
       if (tid == 0) s_max_sims = 0;
@@ -181,10 +201,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
         const float logit = sub < 9 ? out_logits[slot * TTT_ACTIONS + sub] : 0.0f;
         const float prob = row_softmax9(logit, sub);
         const double value = (double)out_value[slot];
+        const int base0 = node_count;
         node_count = expand_row(p, t, leaf, leaf_meta, leaf_sb, prob, sub, node_count);
         backup_cached(t, rc, my_node, my_n, my_vs, path_len, value, sub, win0);
         row_memory_fence();
-        if (path_len <= 2) root_cache_load(rc, t, root, sub);   // the root or one of its children got children
+        expanded_near_root(rc, t, root, sub, path_len, win0, base0, node_count, leaf_meta, leaf_sb);
         --sims_left;
         ++cyc_sims;
         ++n_sim;
@@ -254,7 +275,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
           root_cache_load(rc, t, root, sub);
           continue;
         }
-        const Descent d = descend_cached(p, t, rc, root, board, sub, my_node, my_n, my_vs, win0);
+        const Descent d = descend_cached(p, t, rc, root, board, sub, my_node, my_n, my_vs, win0, tab, tab_n);
         n_lvl += d.levels;
         n_kid += d.children;
         const int term = ttt_terminal(d.sb);
@@ -272,10 +293,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
           const float* row = p.table + (size_t)ttt_code(d.sb) * 10;
           const float prob = sub < 9 ? row[sub] : 0.0f;
           const double value = (double)row[9];
+          const int base0 = node_count;
           node_count = expand_row(p, t, d.node, d.lk.y, d.sb, prob, sub, node_count);
           backup_cached(t, rc, my_node, my_n, my_vs, d.path_len, value, sub, win0);
           row_memory_fence();
-          if (d.path_len <= 2) root_cache_load(rc, t, root, sub);
+          expanded_near_root(rc, t, root, sub, d.path_len, win0, base0, node_count, d.lk.y, d.sb);
           --sims_left;
           ++cyc_sims;
           ++n_sim;

@@ -175,15 +175,22 @@ template <int N>
 __device__ __forceinline__ double row_ror(double v) {
   return __hiloint2double(row_ror<N>(__double2hiint(v)), row_ror<N>(__double2loint(v)));
 }
-// one butterfly step of the row-wide max over (score, key); key = action << 8 | lane
-template <int N>
-__device__ __forceinline__ void argmax_step(double& score, int& key) {
-  const double os = row_ror<N>(score);
-  const int ok = row_ror<N>(key);
-  if (os > score || (os == score && ok > key)) {
-    score = os;
-    key = ok;
-  }
+// Row-wide argmax of (score, action): the larger action wins a tie (Explorer.py:100: max over (score, action, child)
+// tuples).  Children sit in ascending action order, lane j = child j, so that is: the highest lane among those that
+// hold the maximum.  Two butterflies of four DPP rotations: the maximum score (v_max_f64), then the highest lane
+// whose score equals it (v_max_i32).  Lanes that hold no child pass score = -inf.
+__device__ __forceinline__ int row_argmax(double score, int sub) {
+  double m = score;
+  m = fmax(m, row_ror<8>(m));
+  m = fmax(m, row_ror<4>(m));
+  m = fmax(m, row_ror<2>(m));
+  m = fmax(m, row_ror<1>(m));
+  int win = (score == m) ? sub : -1;
+  win = max(win, row_ror<8>(win));
+  win = max(win, row_ror<4>(win));
+  win = max(win, row_ror<2>(win));
+  win = max(win, row_ror<1>(win));
+  return win;
 }
 
 // One descent from `root` (Explorer.py:51-58).  On return `node`/`lk` is the
@@ -220,7 +227,6 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, Arena t, int
     const double cb = p.bias_tab[n_parent];
     const bool negate = (int)meta_to_play(d.lk.y) == p.negate_player;
     double score = -INFINITY;
-    int key = -1;
     int n = 0;
     uint2 clk = make_uint2(0u, 0u);
     if (sub < k) {
@@ -228,18 +234,12 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, Arena t, int
       n = c.visit;
       clk = make_uint2(c.first, c.meta);
       score = puct_score(p, sq, cb, negate, n, c.q, c.prior);
-      key = ((int)meta_action(clk.y) << 8) | sub;
     }
-    // max over (score, action): the larger action wins a tie (Explorer.py:100)
-    argmax_step<8>(score, key);
-    argmax_step<4>(score, key);
-    argmax_step<2>(score, key);
-    argmax_step<1>(score, key);
-    const int win = key & 0xff;
+    const int win = row_argmax(score, sub);
     clk.x = (uint32_t)row_geti((int)clk.x, win);
     clk.y = (uint32_t)row_geti((int)clk.y, win);
     n_parent = row_geti(n, win);
-    d.sb = ttt_step(d.sb, key >> 8);
+    d.sb = ttt_step(d.sb, (int)meta_action(clk.y));
     d.node = base + win;
     d.lk = clk;
     if (sub == d.path_len) my_node = d.node;
@@ -288,9 +288,10 @@ __device__ __forceinline__ void root_cache_load(RootCache& c, Arena t, int root,
 }
 // As descend_row; additionally lane i receives path node i's (visit, value_sum) as read
 // during the descent (my_n, my_vs) and win0 is the lane of the chosen root child (-1: none).
+// `tab` (may be null): the first `tab_n` entries of (sqrt_tab, bias_tab) interleaved, in LDS.
 __device__ __forceinline__ Descent descend_cached(const TreeParams& p, Arena t, const RootCache& c, int root,
                                                   uint32_t board, int sub, int& my_node, int& my_n, double& my_vs,
-                                                  int& win0) {
+                                                  int& win0, const double2* tab = nullptr, int tab_n = 0) {
   Descent d;
   d.node = root;
   d.sb = board;
@@ -314,11 +315,16 @@ __device__ __forceinline__ Descent descend_cached(const TreeParams& p, Arena t, 
       if (sub == 0) atomicOr(p.error_flag, 2);
       break;
     }
-    const double sq = p.sqrt_tab[n_parent];
-    const double cb = p.bias_tab[n_parent];
+    double sq, cb;
+    if (n_parent < tab_n) {
+      const double2 e = tab[n_parent];
+      sq = e.x; cb = e.y;
+    } else {
+      sq = p.sqrt_tab[n_parent];
+      cb = p.bias_tab[n_parent];
+    }
     const bool negate = (int)meta_to_play(d.lk.y) == p.negate_player;
     double score = -INFINITY;
-    int key = -1;
     int n = 0;
     double vs = 0.0;
     uint2 clk = make_uint2(0u, 0u);
@@ -332,19 +338,14 @@ __device__ __forceinline__ Descent descend_cached(const TreeParams& p, Arena t, 
         clk = make_uint2(ch.first, ch.meta);
       }
       score = puct_score(p, sq, cb, negate, n, q, pr);
-      key = ((int)meta_action(clk.y) << 8) | sub;
     }
-    argmax_step<8>(score, key);
-    argmax_step<4>(score, key);
-    argmax_step<2>(score, key);
-    argmax_step<1>(score, key);
-    const int win = key & 0xff;
+    const int win = row_argmax(score, sub);
     if (d.path_len == 1) win0 = win;
     clk.x = (uint32_t)row_geti((int)clk.x, win);
     clk.y = (uint32_t)row_geti((int)clk.y, win);
     n_parent = row_geti(n, win);
     const double vs_win = row_get(vs, win);
-    d.sb = ttt_step(d.sb, key >> 8);
+    d.sb = ttt_step(d.sb, (int)meta_action(clk.y));
     d.node = base + win;
     d.lk = clk;
     if (sub == d.path_len) {
