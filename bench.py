@@ -8,26 +8,34 @@ end on G concurrent game trees (slots that finish a game take the next one, as
 the reference's ActorPool does), S MCTS simulations per move, network fused
 into the search (BASELINE.json configs[1]: 100 sims/move, 4096 concurrent games,
 1 x MI355X; default R = 4 G), followed -- when N > 1 -- by the RCCL gather of the
-finished games to rank 0's replay buffer.  Weights are synthetic (random-init
-RecurrentNet(2,1,64,2), seed 0); games need no dataset.  Prints ONE JSON line on
-rank 0.
+finished games to rank 0's replay buffer (and preceded, once, by the broadcast of
+the weights from rank 0).  Weights are synthetic (random-init RecurrentNet(2,1,64,2),
+seed 0); games need no dataset.  Prints ONE JSON line on rank 0.
 
-Extra keys
+Extra keys (N = 1)
   expansions_per_s, simulations_per_s   the metric's second half
-  roofline          the dominant kernel: the persistent self-play kernel, priced
-                    against the FP32 MFMA peak with the network's algorithmic
-                    FLOPs (in-bounds taps only) over the kernel's HIP-event time
-  roofline_net      the fused network kernel alone (4096 positions per launch)
-  roofline_select   the lock-step tree kernel (select + expand + backup) against
-                    HBM, SURVEY.md 8(d) byte counts
+  roofline          the dominant kernel, selfplay_kernel, against the dense BF16 MFMA peak: achieved = the bf16 MFMA
+                    FLOPs it executes (six split terms per float32 product) over its HIP-event time; the
+                    algorithmic float32 figure (in-bounds taps only) is the sub-key `algorithmic_f32`;
+                    `traffic` = HBM bytes per launch from rocprofv3 PMC passes, quoted (with the commit they were
+                    measured at) only for the configuration they were collected on
+  roofline_tree_phase  the tree phases of the same kernel against HBM: algorithmic select / backup / expand bytes
+                     from the run's own counters over the stamped tree-phase time
+  roofline_net      the fused network kernel alone (4096 positions per launch), BF16 MFMA peak
+  roofline_select   the lock-step tree kernel advance_kernel (select + expand + backup, table evaluator) against HBM --
+                    NOT on the product route (the persistent kernel does this work in its tree phases)
   phases            in-kernel shader-clock shares of the stamped diagnostic build
-  cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the
-                    restatement of the reference's Explorer/Gamer path) timed on
-                    this box's host cores on a bounded sample
+  scs_config4       BASELINE.json configs[3]: SCS 5x5, ConvNet(32 filters x 8 layers, square convs), 200 sims/move,
+                    1024 concurrent games, one whole round in the library (nz_scs_search_play)
+  gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
+                    save_game for every game, statistics), games/s
+  cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
+                    Explorer/Gamer path) on this box's host cores, one process per core, on a bounded sample
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -41,9 +49,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16 matrix peak (dense)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak
 
 
-def cpu_baseline(sims, seconds=15.0):
-    """The CPU oracle on a bounded sample of the same workload: whole games at
-    `sims` simulations/move, one process, one torch thread."""
+def _cpu_worker(args):
+    """One process, one core: whole games at `sims` simulations/move until `seconds` are over."""
+    worker, sims, seconds = args
     import torch
     from oracle import ttt as ottt, search as osearch
     from oracle.net import RecurrentNetRef
@@ -57,15 +65,101 @@ def cpu_baseline(sims, seconds=15.0):
     games = expansions = simulations = 0
     while time.perf_counter() - t0 < seconds:
         g = ottt.TicTacToe()
-        _, cnt = osearch.play_game(g, ev, cfg, np.random.RandomState(games))
+        _, cnt = osearch.play_game(g, ev, cfg, np.random.RandomState(worker * 100000 + games))
         games += 1
         expansions += cnt.expansions
         simulations += cnt.simulations
+    return games, expansions, simulations, time.perf_counter() - t0
+
+
+def cpu_baseline(sims, seconds=15.0, max_procs=64):
+    """The CPU oracle on a bounded sample of the same workload: one process per host core this job may run on
+    (torch: 1 thread each), whole games at `sims` simulations/move for `seconds`."""
+    import multiprocessing as mp
+    cores = min(len(os.sched_getaffinity(0)), max_procs)
+    with mp.get_context("spawn").Pool(cores) as pool:
+        parts = pool.map(_cpu_worker, [(w, sims, seconds) for w in range(cores)])
+    games = sum(p[0] for p in parts)
+    dt = max(p[3] for p in parts)
+    return {"value": games / dt, "unit": "games/s", "cores": cores, "kind": "port",
+            "expansions_per_s": sum(p[1] for p in parts) / dt, "simulations_per_s": sum(p[2] for p in parts) / dt,
+            "per_core_games_per_s": games / dt / cores,
+            "sample": f"{games} whole games, {sims} sims/move, {dt:.1f} s on {cores} host cores, one process per core "
+                      f"(python oracle + torch fp32 net, 1 thread each)"}
+
+
+def git_commit():
+    try:
+        return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
+                                       text=True).strip()
+    except Exception:
+        return None
+
+
+def scs_config4(device):
+    """BASELINE.json configs[3] (square-conv form, the pinned one): one whole self-play round, in-library move loop."""
+    import torch
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    cfg = ScsGameConfig(os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
+    search = {"Simulation": {"mcts_simulations": 200, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
+    G = 1024
+    net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=8, max_batch=G, device=device)
+    net.set_weights(synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 8)))
+    sp = ScsSelfPlay(cfg, search, G, device=device)
+    sp.play_native(net, range(G), max_moves=2)            # warm-up: first launches, allocations
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = sp.play_native(net, range(10 ** 6, 10 ** 6 + G))
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": games / dt, "unit": "games/s", "cores": 1, "kind": "port",
-            "expansions_per_s": expansions / dt, "simulations_per_s": simulations / dt,
-            "sample": f"{games} whole games, {sims} sims/move, seeds 0..{games - 1}, "
-                      f"{dt:.1f} s on 1 host core (python oracle + torch fp32 net, 1 thread)"}
+    out = {"value": G / dt, "unit": "games/s", "expansions_per_s": r["expansions"] / dt,
+           "simulations_per_s": r["simulations"] / dt, "seconds": dt, "waves": r["waves"],
+           "net_tflops_algorithmic": r["expansions"] * net.flops_per_position / dt / 1e12,
+           "workload": "SCS mirrored 5x5 map (stack 2, 86 planes, 525 actions), ConvNet(32 filters, 8 layers, 3x3 square "
+                       "convs), 200 sims/move, 1024 concurrent self-play games, a1 search config, 1 GPU"}
+    sp.close()
+    net.close()
+    return out
+
+
+def gamer_surface(cfg, weights, games, n_round, device, rounds=2):
+    """The reference-shaped worker round: Gamer.play_games = search + ReplayBuffer.save_game for every game + the six
+    statistics per game, with the replay buffer on the device; then one training batch is drawn."""
+    import torch
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.replay_device import DeviceReplayBuffer
+
+    class tic_tac_toe:
+        pass
+
+    rb = DeviceReplayBuffer(window_size=4 * n_round, batch_size=2048, state_shape=(2, 3, 3), num_actions=9,
+                            max_game_length=9, device=device)
+    g = Gamer(rb, Network_Manager(weights), tic_tac_toe, [], 0, cfg, 2, "disabled", num_games=n_round,
+              concurrent_games=games, device=device, base_seed=5 * 10 ** 6, records=False)
+    g.play_games()                                         # warm-up round
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(rounds):
+        _, stats = g.play_games()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    batch = rb.get_sample(2048, True, [], group_by_game=True)
+    torch.cuda.synchronize()
+    out = {"value": rounds * n_round / dt, "unit": "games/s", "rounds": rounds, "games_per_round": n_round,
+           "buffer_positions": rb.len(), "sample_2048_ms": (time.perf_counter() - t1) * 1e3,
+           "includes": "nz_engine_play, export, nz_replay_append of every position, per-game statistics dicts"}
+    assert len(stats) == n_round and len(batch) == 2048
+    rb.close()
+    g.engine.close()
+    return out
 
 
 def main():
@@ -83,24 +177,32 @@ def main():
     args = ap.parse_args()
     n_round = args.round if args.round > 0 else 4 * args.games
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    # the CPU baseline runs first, in worker processes, before this process touches the GPU
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.sims, args.cpu_seconds)
+
     import torch
     from nuzero_amd.engine import SelfPlayEngine
     from nuzero_amd.weights import synthetic_recurrent_net_weights
     from nuzero_amd.search_config import legacy_ttt_search_config
     from nuzero_amd import dist as nzdist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as td
         td.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = legacy_ttt_search_config(args.sims)
-    weights = synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True)
+    # the rank that would train owns the weights; one broadcast hands them to every self-play rank (Gamer.py:40,61)
+    weights = synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True) if rank == 0 else None
+    weights = nzdist.broadcast_weights(weights, src=0, device=torch.device("cuda", local_rank)) if world > 1 else weights
     eng = SelfPlayEngine(cfg, n_round, training=True, device=local_rank, n_slots=args.games)
     eng.set_weights(weights, recurrent_iterations=args.iters)
     gather = nzdist.ReplayGather(eng, world, rank) if world > 1 else None
@@ -144,28 +246,39 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "arithmetic": "network: float32 values, every product formed from six bf16 MFMA terms on exact three-way "
-                      "splits, float32 accumulation (as accurate as a float32 convolution, DESIGN.md section 4); "
+                      "splits, float32 accumulation (as accurate as a float32 convolution, DESIGN.md section 5); "
                       "tree statistics float64",
         "config": {"workload": "Tic_Tac_Toe, %d sims/move, %d concurrent self-play games per GPU (%d games per "
                                "round), RecurrentNet(2,1,64,2) %d recurrent iterations f32, tree statistics f64, "
                                "legacy TTT search config" % (args.sims, args.games, n_round, args.iters),
                    "concurrent_games_per_gpu": args.games, "games_per_round_per_gpu": n_round,
                    "sims_per_move": args.sims,
-                   "parallelism": "games sharded by rank, 1 RCCL gather per round" if world > 1 else "1 GPU"},
+                   "parallelism": "games sharded by rank, weights broadcast once, 1 RCCL gather per round"
+                                  if world > 1 else "1 GPU"},
         "expansions_per_s": exp_total / dt, "simulations_per_s": sims_total / dt,
+        "commit": git_commit(),
     }
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:
         flops_pos = eng.net_flops_per_position()
         bf16_pos, f32_pos = eng.net_matrix_flops_per_position()
 
-        def executed(tflops_algorithmic):
-            """The same time priced by the MFMA instructions actually issued."""
-            scale = tflops_algorithmic / flops_pos
-            return {"bf16_mfma_tflops": scale * bf16_pos, "bf16_mfma_peak": MFMA_BF16_PEAK_TFLOPS,
-                    "bf16_mfma_frac": scale * bf16_pos / MFMA_BF16_PEAK_TFLOPS,
-                    "f32_mfma_tflops": scale * f32_pos,
-                    "matrix_flops_per_position": {"bf16": bf16_pos, "f32": f32_pos}}
+        def mfma_roofline(kernel, positions, ms, launches, traffic=None, traffic_at=None):
+            """A kernel that runs the fused network: priced by the bf16 MFMAs it issues against the dense BF16 peak."""
+            executed = positions * bf16_pos / (ms * 1e-3) / 1e12
+            return {"bound": "mfma", "kernel": kernel, "achieved": executed, "peak": MFMA_BF16_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": executed / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_measured_at": traffic_at,
+                    "achieved_note": "bf16 MFMA FLOPs executed (v_mfma_f32_16x16x32_bf16, six split terms per float32 "
+                                     "product, zero-padded channels of 32-channel K groups included)",
+                    "avg_launch_us": ms * 1e3 / max(launches, 1), "launches": launches,
+                    "positions_per_launch": positions / max(launches, 1),
+                    "matrix_flops_per_position": {"bf16": bf16_pos, "f32": f32_pos},
+                    "algorithmic_f32": {"tflops": positions * flops_pos / (ms * 1e-3) / 1e12,
+                                        "flops_per_position": flops_pos,
+                                        "note": "float32 conv FLOPs of the network, in-bounds taps only; for scale: "
+                                                "the FP32 MFMA peak is %.1f TFLOP/s" % MFMA_F32_PEAK_TFLOPS}}
+
         # ---- dominant kernel: HIP events around the persistent kernel, on its own stream, one more round
         eng.profile(True)
         eng.play(base_seed=10 ** 6 + rank * n_round)
@@ -173,27 +286,43 @@ def main():
         eng.profile(False)
         pc = eng.counters()
         k_ms, k_n = prof["search"]["ms"], prof["search"]["launches"]
-        achieved = pc["expansions"] * flops_pos / (k_ms * 1e-3) / 1e12
-        # HBM bytes per launch of this kernel from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs,
-        # profiles/r01_pmc_traffic.json); only quoted for the configuration they were collected on
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and (args.games, n_round, args.sims, args.iters) == (4096, 16384, 100, 2):
+        # HBM bytes per launch from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, corrected as the
+        # guide prescribes): a stored measurement, quoted with its commit, only for the configuration it was made on
+        traffic = traffic_at = None
+        tpath = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_raw"]
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
-            "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-            "peak_note": "float32 dense MFMA peak: what a kernel doing this float32 arithmetic on the FP32 matrix "
-                         "cores could reach; the kernel issues bf16 MFMAs instead, see `executed`",
-            "flops_per_position": flops_pos, "positions_per_launch": pc["expansions"] / max(k_n, 1),
-            "avg_launch_us": k_ms * 1e3 / max(k_n, 1), "launches": k_n, "executed": executed(achieved)}
-    if not args.no_extras and world == 1:
-        # ---- in-kernel phase shares (stamped diagnostic build; its run time is not quoted)
+                tj = json.load(f)
+            if tj.get("config") == [args.games, n_round, args.sims, args.iters]:
+                traffic, traffic_at = tj["hbm_bytes_per_launch"], tj.get("commit")
+        out["roofline"] = mfma_roofline("selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
+                                        pc["expansions"], k_ms, k_n, traffic, traffic_at)
+
+        # ---- in-kernel phase shares (stamped diagnostic build; its run time is only used for the tree-phase figure)
         eng.phase_stamps(True)
+        eng.profile(True)
         eng.play(base_seed=2 * 10 ** 6 + rank * n_round)
-        out["phases"] = eng.phase_stamps(False, read=True)
+        sp_ms = eng.profile_read()["search"]["ms"]
+        eng.profile(False)
+        ph = eng.phase_stamps(False, read=True)
+        out["phases"] = ph
+        tc = eng.counters()
+        # SURVEY.md 8(d) algorithmic bytes: select 11 + 20 k per scored node with k children; backup 24 per path
+        # node (levels + 1 per simulation); expand 5 A + 7 per expansion + 22 per child created (A = 9)
+        sel_b = 11 * tc["select_nodes"] + 20 * tc["select_children"]
+        bak_b = 24 * (tc["select_nodes"] + tc["simulations"])
+        exp_b = (5 * 9 + 7) * tc["expansions"] + 22 * tc["new_nodes"]
+        tree_s = sp_ms * 1e-3 * ph["tree_share"] * ph["mean_over_max_lifetime"]
+        tree_gbs = (sel_b + bak_b + exp_b) / tree_s / 1e9
+        out["roofline_tree_phase"] = {
+            "bound": "hbm", "kernel": "selfplay_kernel, tree phases (select + backup + expand + move bookkeeping of 16 "
+                                      "games per workgroup between two network passes)",
+            "achieved": tree_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": tree_gbs / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes": {"select": sel_b, "backup": bak_b, "expand": exp_b},
+            "tree_phase_seconds": tree_s, "simulations_per_s_in_phase": tc["simulations"] / tree_s,
+            "note": "latency-bound, not bandwidth-bound: one simulation at a time per tree (Explorer.py:49-61), 16 trees "
+                    "per CU, every level a dependent load; the phase is %.0f %% of the kernel" % (100 * ph["tree_share"])}
+
         # ---- the network kernel alone
         x = (torch.rand((4096, 2, 3, 3), device="cuda") > 0.6).float()
         eng.net_forward(x, want_probs=False)
@@ -203,14 +332,11 @@ def main():
             eng.net_forward(x, want_probs=False)
         pn = eng.profile_read()["network"]
         eng.profile(False)
-        net_tf = 20 * 4096 * flops_pos / (pn["ms"] * 1e-3) / 1e12
-        out["roofline_net"] = {"bound": "mfma", "kernel": "net_kernel (fused RecurrentNet forward, 4096 positions)",
-                               "achieved": net_tf, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": net_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                               "avg_launch_us": pn["ms"] * 1e3 / 20, "executed": executed(net_tf)}
-        # ---- the tree kernel alone against HBM (SURVEY.md 8d bytes: 11 + 20 k per scored node, 24 per
-        #      path node backed up): lock-step route with a table evaluator, so advance_kernel does a whole
-        #      move's select/expand/backup per launch; at the workload's 4096 trees and at 65536 trees
+        out["roofline_net"] = mfma_roofline("net_kernel (fused RecurrentNet forward, 4096 positions)", 20 * 4096,
+                                            pn["ms"], 20)
+
+        # ---- the lock-step tree kernel against HBM (select 11 + 20 k per scored node, backup 24 per path node):
+        #      table evaluator, so advance_kernel does a whole move's select/expand/backup per launch
         rs = np.random.RandomState(0)
         table = np.zeros((3 ** 9, 10), np.float32)
         table[:, :9] = rs.dirichlet(np.ones(9), 3 ** 9)
@@ -226,23 +352,30 @@ def main():
             ls.profile(False)
             lc = ls.counters()
             sel_bytes = (11 * lc["select_nodes"] + 20 * lc["select_children"]
-                         + 24 * (lc["select_nodes"] + lc["simulations"]))
+                         + 24 * (lc["select_nodes"] + lc["simulations"])
+                         + (5 * 9 + 7) * lc["expansions"] + 22 * lc["new_nodes"])
             sel[n_trees] = {"achieved": sel_bytes / (pl["ms"] * 1e-3) / 1e9,
                             "bytes_per_launch": sel_bytes / max(pl["launches"], 1),
                             "avg_launch_us": pl["ms"] * 1e3 / max(pl["launches"], 1), "launches": pl["launches"],
                             "simulations_per_s": lc["simulations"] / (pl["ms"] * 1e-3)}
             ls.close()
         big = sel[65536]
-        out["roofline_select"] = {"bound": "hbm", "kernel": "advance_kernel (select + expand + backup, table evaluator, "
-                                  "65536 concurrent trees)", "achieved": big["achieved"], "peak": HBM_PEAK_GBS,
+        out["roofline_select"] = {"bound": "hbm", "kernel": "advance_kernel (lock-step route: select + expand + backup, "
+                                  "table evaluator, 65536 concurrent trees; not on the product route)",
+                                  "achieved": big["achieved"], "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": big["achieved"] / HBM_PEAK_GBS, "traffic": None,
                                   "bytes_per_launch": big["bytes_per_launch"], "avg_launch_us": big["avg_launch_us"],
                                   "launches": big["launches"], "simulations_per_s": big["simulations_per_s"],
                                   "at_workload_trees": dict(sel[args.games], trees=args.games)}
+        eng.close()
+        # ---- the reference-shaped surface and one SCS configuration, driver-timed
+        out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
+        out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
+        out["scs_config4"] = scs_config4(local_rank)
 
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.sims, args.cpu_seconds)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         td.destroy_process_group()

@@ -218,8 +218,9 @@ nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* e
                              void* stream);
 /* As above plus the select work done: out[0] simulations, out[1] expansions,
  * out[2] internal nodes whose children were scored (descent levels), out[3]
- * children scored.  Used to price the tree kernel's algorithmic bytes. */
-nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream);
+ * children scored, out[4] nodes created by expansions.  Used to price the tree
+ * phase's algorithmic bytes. */
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out5_host, void* stream);
 
 /* Algorithmic FLOPs of one network evaluation (one position): sum over convs of
  * 2 * C_out * C_in * 49, i.e. only the taps that fall inside the 3x3 board. */
@@ -401,6 +402,52 @@ void nz_rng_seed(nz_rng* r, uint32_t seed);
 uint32_t nz_rng_u32(nz_rng* r);
 double nz_rng_double(nz_rng* r);                                  /* random_sample() */
 void nz_rng_gamma(nz_rng* r, double shape, double scale, int32_t n, double* out);  /* gamma(shape, scale, n) */
+
+/* ---- replay buffer on the device ------------------------------------------
+ * The positions of finished games stay in HBM; which physical slot a position takes and which slots a batch reads
+ * is decided by the caller (host logic of Training/ReplayBuffer.py:24-53: window in games with per-position
+ * eviction, shuffle, slice, sample), the library moves the data:
+ *   nz_replay_append  replaces the tuple building of ReplayBuffer.save_game (ReplayBuffer.py:31-36) together with
+ *                     Game.store_search_statistics / make_target (tic_tac_toe.py:177-190, SCS_Game.py:1517-1528):
+ *                     row r of the source (state + the root's visit counts, or ready-made policies, or per-child
+ *                     (action, visit) lists) becomes the position in slot dst_slot[r] (-1: not stored); policy =
+ *                     visit / sum(visits) in double, rounded to float32 as torch.tensor() does (AlphaZero.py:901);
+ *                     value = game_value[r / rows_per_game].
+ *   nz_replay_gather  replaces batch assembly (AlphaZero.py:846-852,892-903: torch.cat of the states, one
+ *                     torch.tensor per target): states [B, state_floats], policies [B, A], values [B], game_index [B]
+ *                     for the physical slots of a batch, in the order given (the caller groups by game index).
+ * All pointers are device pointers; work is enqueued on `stream`. */
+typedef struct nz_replay nz_replay;
+nz_status nz_replay_create(nz_replay** out, int64_t capacity_positions, int32_t state_floats, int32_t num_actions,
+                           int32_t device);
+void nz_replay_destroy(nz_replay* h);
+const char* nz_replay_last_error(const nz_replay* h);
+nz_status nz_replay_dims(const nz_replay* h, int64_t* capacity, int32_t* state_floats, int32_t* num_actions);
+/* exactly one of visits_dev [N, A] int32 / policies_dev [N, A] float32 / (child_action_dev, child_visit_dev
+ * [N, max_children] int32 + n_children_dev [N]) */
+nz_status nz_replay_append(nz_replay* h, const float* states_dev, const int32_t* visits_dev, const float* policies_dev,
+                           const int32_t* child_action_dev, const int32_t* child_visit_dev, const int32_t* n_children_dev,
+                           int32_t max_children, const int32_t* game_value_dev, int32_t rows_per_game,
+                           const int64_t* dst_slot_dev, int64_t n_rows, int32_t game_index, void* stream);
+nz_status nz_replay_gather(nz_replay* h, const int64_t* slots_dev, int64_t batch, float* states_out, float* policies_out,
+                           float* values_out, int32_t* game_index_out, void* stream);
+/* synchronises; NZ_ERR_OVERFLOW if a kernel saw a slot or an action out of range */
+nz_status nz_replay_check(nz_replay* h, void* stream);
+
+/* ---- batched loss ---------------------------------------------------------------
+ * AlphaZero.calculate_loss (Training/AlphaZero.py:891-921) for a whole batch in one launch, with the gradients of the
+ * combined loss: losses3 = (value_loss, policy_loss, combined_loss); dlogits [B, A], dvalues [B] may be NULL.
+ * policy_loss: cross entropy with label smoothing 0.02 (AlphaZero.py:327), KL divergence, masked MSE
+ * (Utils/Functions/loss_functions.py:7-26); value_loss: squared / absolute error (loss_functions.py:28-33);
+ * normalize_policy: divide the policy loss by log(batch) as the reference does (AlphaZero.py:912-915).
+ * workspace_dev: 2 * batch floats.  float32 arithmetic; results agree with the reference's to ~1e-6 relative. */
+enum { NZ_LOSS_CE = 0, NZ_LOSS_KLD = 1, NZ_LOSS_MSE = 2 };
+enum { NZ_LOSS_SE = 0, NZ_LOSS_AE = 1 };
+nz_status nz_loss_forward_backward(const float* logits_dev, const float* values_dev, const float* target_policies_dev,
+                                   const float* target_values_dev, int32_t batch, int32_t actions, int32_t policy_loss,
+                                   int32_t value_loss, int32_t normalize_policy, float* losses3_dev, float* dlogits_dev,
+                                   float* dvalues_dev, float* workspace_dev, void* stream);
+const char* nz_loss_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,8 @@ NZ_OK, NZ_ERR_ARG, NZ_ERR_HIP, NZ_ERR_STATE, NZ_ERR_OVERFLOW = range(5)
 NZ_GAME_TIC_TAC_TOE = 0
 NZ_ACT_TANH, NZ_ACT_RELU = 0, 1
 NZ_ARCH_RECURRENT, NZ_ARCH_RESNET, NZ_ARCH_CONVNET = 0, 1, 2
+NZ_LOSS_CE, NZ_LOSS_KLD, NZ_LOSS_MSE = 0, 1, 2
+NZ_LOSS_SE, NZ_LOSS_AE = 0, 1
 
 
 class SearchCfg(Structure):
@@ -121,6 +123,17 @@ SIGNATURES = {
     "nz_scs_search_play_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "nz_scs_search_waves": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_scs_search_phase_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "nz_replay_create": (c_int32, [POINTER(c_void_p), c_int64, c_int32, c_int32, c_int32]),
+    "nz_replay_destroy": (None, [c_void_p]),
+    "nz_replay_last_error": (c_char_p, [c_void_p]),
+    "nz_replay_dims": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int32), POINTER(c_int32)]),
+    "nz_replay_append": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                   c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p]),
+    "nz_replay_gather": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_replay_check": (c_int32, [c_void_p, c_void_p]),
+    "nz_loss_forward_backward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                                           c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_loss_last_error": (c_char_p, []),
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),

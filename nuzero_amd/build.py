@@ -24,6 +24,8 @@ UNITS = [
     ("scs.hip", ["-ffp-contract=off"]),
     ("scs_search.hip", ["-ffp-contract=off"]),
     ("boardnet.hip", []),
+    ("replay.hip", ["-ffp-contract=off"]),
+    ("loss.hip", []),
     ("rng_host.cpp", ["-ffp-contract=off"]),
 ]
 HEADERS = ["engine.h", "tree_dev.hpp", "net_dev.hpp", "scs_dev.hpp", os.path.join("..", "..", "include", "nuzero_amd.h")]

@@ -59,6 +59,7 @@ struct TreeParams {
   int32_t* exp_count;
   int32_t* sel_nodes;     // descent levels (internal nodes scored)
   int32_t* sel_children;  // children scored
+  int32_t* new_nodes;     // nodes created by the game's expansions (sum of the children counts)
   int32_t* n_root_children;
   int32_t* desync;        // 1: the host's pre-drawn randomness did not fit this game (selfplay.hip)
   // leaf queue feeding the network kernel

@@ -308,7 +308,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   A(p.nodes, N);
   A(p.board, G); A(p.length, G); A(p.alive, G); A(p.outcome, G); A(p.root, G); A(p.node_count, G);
   A(p.sims_left, G); A(p.pending, G); A(p.leaf_board, G); A(p.path, G * MAX_PATH); A(p.path_len, G);
-  A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.desync, G); A(p.n_root_children, G);
+  A(p.sim_count, G); A(p.exp_count, G); A(p.sel_nodes, G); A(p.sel_children, G); A(p.new_nodes, G); A(p.desync, G); A(p.n_root_children, G);
   A(p.leaf_count, 2); A(p.leaf_boards, G); A(e->leaf_logits, G * TTT_ACTIONS); A(e->leaf_value, G);
   A(p.error_flag, 1);
   A(p.hist_board, GT); A(p.hist_action, GT); A(p.hist_visits, GTA); A(p.hist_tree_size, GT);
@@ -784,7 +784,7 @@ static nz_status replay_desynced(nz_engine* e, const std::vector<int>& games, ui
     ROW(hist_visits, TTT_MAX_MOVES * TTT_ACTIONS); ROW(hist_prior, TTT_MAX_MOVES * TTT_ACTIONS);
     ROW(hist_value_sum, TTT_MAX_MOVES * TTT_ACTIONS);
     ROW(length, 1); ROW(outcome, 1); ROW(board, 1);
-    ROW(sim_count, 1); ROW(exp_count, 1); ROW(sel_nodes, 1); ROW(sel_children, 1);
+    ROW(sim_count, 1); ROW(exp_count, 1); ROW(sel_nodes, 1); ROW(sel_children, 1); ROW(new_nodes, 1);
 #undef ROW
   }
   NZ_HIP(e, hipStreamSynchronize(s));
@@ -935,12 +935,13 @@ nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* e
   return NZ_OK;
 }
 
-nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream) {
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out5_host, void* stream) {
+  int64_t* const out4_host = out5_host;
   if (!e || !out4_host) return NZ_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  const int32_t* src[4] = {e->tp.sim_count, e->tp.exp_count, e->tp.sel_nodes, e->tp.sel_children};
+  const int32_t* src[5] = {e->tp.sim_count, e->tp.exp_count, e->tp.sel_nodes, e->tp.sel_children, e->tp.new_nodes};
   std::vector<int32_t> h(e->n_games);
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < 5; ++i) {
     NZ_HIP(e, hipMemcpyAsync(h.data(), src[i], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     NZ_HIP(e, hipStreamSynchronize(s));
     int64_t sum = 0;

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
             p.exp_count[g] = n_exp;
             p.sel_nodes[g] = n_lvl;
             p.sel_children[g] = n_kid;
+            p.new_nodes[g] = node_count - 1;
           }
           int ng = 0;
           if (sub == 0) ng = atomicAdd(p.next_game, 1);

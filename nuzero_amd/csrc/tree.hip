@@ -38,6 +38,7 @@ __global__ void reset_kernel(TreeParams p) {
     p.exp_count[g] = 0;
     p.sel_nodes[g] = 0;
     p.sel_children[g] = 0;
+    p.new_nodes[g] = 0;
     p.desync[g] = 0;
     hist_clear(p, g);
   }
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(BLOCK) void advance_kernel(TreeParams p, int iterat
       p.exp_count[g] += n_exp;
       p.sel_nodes[g] += n_lvl;
       p.sel_children[g] += n_kid;
+      p.new_nodes[g] = node_count - 1;
       if (!want_slot) p.pending[g] = -1;
     }
   }

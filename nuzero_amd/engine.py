@@ -286,10 +286,11 @@ class SelfPlayEngine:
         return out
 
     def counters(self):
-        out = (c_int64 * 4)()
+        out = (c_int64 * 5)()
         with torch.cuda.device(self.device):
             check(lib.nz_engine_counters_ex(self._h, out, _stream()), self._h)
-        return {"simulations": out[0], "expansions": out[1], "select_nodes": out[2], "select_children": out[3]}
+        return {"simulations": out[0], "expansions": out[1], "select_nodes": out[2], "select_children": out[3],
+                "new_nodes": out[4]}
 
     # ---- kernel timing -----------------------------------------------------------
     def profile(self, enable=True):

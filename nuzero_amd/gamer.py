@@ -70,6 +70,25 @@ class DisabledCache:
         return None
 
 
+def round_stats(r):
+    """game_stats for every game of an export at once (numpy): a list of the reference's statistics dicts."""
+    lengths = np.asarray(r["lengths"], np.int64)
+    G, T = r["tree_size"].shape
+    live = np.arange(T)[None, :] < lengths[:, None]
+    ts = np.where(live, r["tree_size"], 0).astype(np.int64)
+    ch = np.where(live, r["n_children"], 0).astype(np.int64)
+    bias = np.where(live, r["bias"], 0.0)
+    acc = np.add.accumulate(bias, axis=1)                       # left to right: the reference's += in move order
+    last = np.maximum(lengths - 1, 0)
+    rows = np.arange(G)
+    n = np.maximum(lengths, 1)
+    cols = (lengths.tolist(), (ch.sum(1) / n).tolist(), (ts.sum(1) / n).tolist(), ts[rows, last].tolist(),
+            (acc[rows, last] / n).tolist(), r["bias"][rows, last].tolist())
+    keys = ("number_of_moves", "average_children", "average_tree_size", "final_tree_size", "average_bias_value",
+            "final_bias_value")
+    return [dict(zip(keys, row)) for row in zip(*cols)]
+
+
 def game_stats(r, g):
     """The statistics dict of Gamer.py:42-50,81-92 for game g of an export."""
     n = int(r["lengths"][g])
@@ -90,7 +109,7 @@ def game_stats(r, g):
 class Gamer:
     def __init__(self, buffer, shared_storage, game_class, game_args, game_index, search_config,
                  recurrent_iterations, cache_choice="disabled", size_estimate=10000,
-                 num_games=1, concurrent_games=None, device=0, base_seed=0):
+                 num_games=1, concurrent_games=None, device=0, base_seed=0, records=True):
         """Arguments up to `size_estimate` are the reference's (Gamer.py:20).
         `shared_storage` is anything with ``get()`` returning a Network_Manager (or
         the Network_Manager itself); `buffer` anything with ``save_game(game, i)``
@@ -111,6 +130,9 @@ class Gamer:
         self.base_seed = base_seed
         self.time_to_stop = False
         self.device = device
+        # records=False: play_games returns no per-game record objects (a round of 16 k games is 115 k Python lists);
+        # with a device replay buffer (`buffer.save_games_from_engine`) the positions then never visit the host
+        self.records = records
         self._loaded = None
         self._wrapped = None
         if self.is_scs:
@@ -154,11 +176,24 @@ class Gamer:
             self._loaded = (id(nm), nm.version)
         self.engine.play(base_seed=self.base_seed)
         self.base_seed += self.num_games
-        r = self.engine.export()
+        on_device = hasattr(self.buffer, "save_games_from_engine")
+        if on_device:
+            # replay buffer in HBM: states, visit counts and outcomes go from the engine's export buffers into the
+            # buffer's slots on the device (ReplayBuffer.save_game for every game of the round, in order)
+            ex = self.engine.export_device()
+            self.buffer.save_games_from_engine(self.engine, self.game_index, export=ex)
+            if not self.records:
+                r = {k: ex[k].cpu().numpy() for k in ("lengths", "tree_size", "n_children", "bias")}
+                return [], round_stats(r)
+            r = {k: (v.cpu().numpy() if v is not None else None) for k, v in ex.items()}
+        else:
+            r = self.engine.export(states=self.records)
+        stats = round_stats(r)
+        if not self.records:
+            return [], stats
         records = [GameRecord(r["states"][g], r["visits"][g], r["actions"][g], r["lengths"][g], r["outcomes"][g])
                    for g in range(self.num_games)]
-        stats = [game_stats(r, g) for g in range(self.num_games)]
-        if self.buffer is not None:
+        if self.buffer is not None and not on_device:
             for rec in records:
                 self.buffer.save_game(rec, self.game_index)
         return records, stats
@@ -174,9 +209,14 @@ class Gamer:
             self._loaded = (id(nm), nm.version)
         r = self.engine.play_native(self._board_net, range(self.base_seed, self.base_seed + self.num_games))
         self.base_seed += self.num_games
+        stats = round_stats(r)
+        on_device = hasattr(self.buffer, "save_scs_games")
+        if on_device:
+            self.buffer.save_scs_games(self.engine, self.engine.export_device(), self.game_index)
+        if not self.records:
+            return [], stats
         records = scs_game_records(self.engine, r)
-        stats = [game_stats(r, g) for g in range(self.num_games)]
-        if self.buffer is not None:
+        if self.buffer is not None and not on_device:
             for rec in records:
                 self.buffer.save_game(rec, self.game_index)
         return records, stats

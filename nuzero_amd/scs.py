@@ -272,7 +272,8 @@ class ScsSelfPlay:
         self._check(lib.nz_scs_search_phase_ticks(self._h, out))
         return dict(zip(("expand", "rules_copy", "clone", "descent", "leaf_mask_image", "terminal_sims"), [int(v) for v in out]))
 
-    def export(self):
+    def export_device(self):
+        """The finished round as device tensors (what the device replay buffer and the multi-GPU gather read)."""
         G, M, C = self.n_games, self.MAX_MOVES, self.MAX_CHILDREN
         dev = self.device
         t = {"actions": torch.empty((G, M), dtype=torch.int32, device=dev),
@@ -288,11 +289,14 @@ class ScsSelfPlay:
         self._check(lib.nz_scs_search_export(self._h, *[c_void_p(t[k].data_ptr()) for k in (
             "actions", "tree_size", "n_children", "bias", "root_value_sum", "child_action", "child_visit",
             "child_prior", "child_value_sum")], counters, self._stream()))
-        out = {k: v.cpu().numpy() for k, v in t.items()}
-        st = self.status()
-        out["lengths"], out["outcomes"] = st[:, 6].copy(), st[:, 5].copy()
-        out["simulations"], out["expansions"] = int(counters[0]), int(counters[1])
-        return out
+        st = torch.empty((G, 7), dtype=torch.int32, device=dev)
+        self._check(lib.nz_scs_search_status(self._h, c_void_p(st.data_ptr()), self._stream()))
+        t["lengths"], t["outcomes"] = st[:, 6].contiguous(), st[:, 5].contiguous()
+        t["simulations"], t["expansions"] = int(counters[0]), int(counters[1])
+        return t
+
+    def export(self):
+        return {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in self.export_device().items()}
 
 
 def torch_evaluator(model, recurrent_iterations=2, pad_to=None):

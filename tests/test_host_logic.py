@@ -216,3 +216,174 @@ def test_network_manager_follows_in_place_weight_updates():
     d.model["projection.0.weight"] = w1["projection.0.weight"]
     assert d.refresh() == d.version and np.array_equal(d.state_dict()["projection.0.weight"], w1["projection.0.weight"])
     nm.model_to_cpu(); nm.model_to_device(); nm.check_devices()   # surface of Network_Manager.py:32-44
+
+
+def test_replay_buffer_checkpoint_in_the_reference_layout(tmp_path):
+    """save_to_file / load_from_file use the reference's layout {'buffer', 'map', 'partial_loading'} and its loading
+    rule by training step (ReplayBuffer.py:64-107); a file laid out the way the reference's save_to_file writes it
+    loads (with torch.load(weights_only=True))."""
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    rb = ReplayBuffer(window_size=3, batch_size=4)
+    rb.save_game(_Rec(4, 1), 0)
+    rb.save_to_file(tmp_path / "a.pt", step=10)
+    rb.save_game(_Rec(2, 2), 1)
+    rb.save_to_file(tmp_path / "a.pt", step=20)
+    raw = torch.load(tmp_path / "a.pt", weights_only=True)
+    assert set(raw) == {"buffer", "map", "partial_loading"} and raw["map"] == {10: (4, 1), 20: (6, 2)} and raw["partial_loading"]
+    other = ReplayBuffer(3, 4)
+    other.load_from_file(tmp_path / "a.pt", step=10)
+    assert other.len() == 5 and other.played_games() == 1          # buffer[:buffer_len + 1], as the reference slices
+    other.load_from_file(tmp_path / "a.pt", step=20)
+    assert other.len() == 6 and other.played_games() == 2
+    with pytest.raises(Exception):
+        other.load_from_file(tmp_path / "a.pt", step=15)
+    # a reference-written file: plain containers, tensors and numbers
+    entry = lambda g, m: (torch.full((1, 2, 3, 3), float(10 * g + m)), (1, [m / 9.0] * 9), g % 2)
+    torch.save({"buffer": [entry(g, m) for g in range(4) for m in range(3)], "map": {5: (6, 2), 9: (12, 3)},
+                "partial_loading": False}, tmp_path / "ref.pt")
+    other.load_from_file(tmp_path / "ref.pt", step=5)              # partial loading off: the whole latest buffer
+    assert other.len() == 12 and other.played_games() == 3 and other.full
+    state, (value, policy), idx = other.get_buffer()[-1]
+    assert float(state.flatten()[0]) == 32.0 and value == 1 and len(policy) == 9 and idx == 1
+    # window full -> partial loading is switched off for good
+    rb.save_game(_Rec(2, 3), 0)
+    rb.save_game(_Rec(2, 4), 0)
+    rb.save_to_file(tmp_path / "b.pt", step=30)
+    assert torch.load(tmp_path / "b.pt", weights_only=True)["partial_loading"] is False
+
+
+def _replay_kat():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "replay_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("name", ["small_window", "never_full", "window_1", "long"])
+def test_replay_index_equals_the_reference(name):
+    """The host side of the device replay buffer (order, window in games with per-position eviction, random.shuffle,
+    slices, np.random.choice samples incl. the late_heavy weights, grouping by game index) against traces of the
+    GENUINE ReplayBuffer class (tests/golden/make_golden_replay.py): same (game, move) identities in the same order."""
+    import random
+    from nuzero_amd.replay_device import ReplayIndex, late_heavy_probs
+    case = _replay_kat()[name]
+    idx = ReplayIndex(case["window"])
+    ident = {}                       # physical slot -> (game, move)
+    for op in case["ops"]:
+        if op["op"] == "save":
+            g = op["game"]
+            dst = idx.save_games([case["lengths"][g]], case["game_types"][g])
+            for m, slot in enumerate(dst[0]):
+                ident[int(slot)] = [g, m]
+            assert len(idx) == op["len"] and idx.n_games == op["played"] and idx.full == op["full"]
+            assert [ident[int(s)] for s in idx.seq] == op["order"]
+        elif op["op"] == "shuffle":
+            random.seed(op["seed"])
+            idx.shuffle()
+            assert [ident[int(s)] for s in idx.seq] == op["order"]
+        elif op["op"] == "slice":
+            got = idx.get_slice(op["start"], op["stop"])
+            assert [ident[int(s)] + [int(idx.slot_game_index[s])] for s in got] == op["got"]
+        elif op["op"] == "sample":
+            probs = late_heavy_probs(len(idx)) if op["late_heavy"] else []
+            np.random.seed(op["seed"])
+            got = idx.get_sample(op["batch_size"], op["replace"], probs)
+            assert [ident[int(s)] + [int(idx.slot_game_index[s])] for s in got] == op["got"]
+        elif op["op"] == "bucket":
+            np.random.seed(op["seed"])
+            slots, keys, counts = idx.bucket(idx.get_sample(op["batch_size"], True, []))
+            assert keys == op["keys"] and counts == [len(g) for g in op["groups"]]
+            flat = [e for g in op["groups"] for e in g]
+            assert [ident[int(s)] + [int(idx.slot_game_index[s])] for s in slots] == flat
+
+
+def test_replay_index_batches_of_games_equal_one_by_one():
+    """save_games(many lengths) == save_games([length]) game after game, also when the window fills inside the batch and
+    when a batch is larger than the whole buffer."""
+    from nuzero_amd.replay_device import ReplayIndex
+    rs = np.random.RandomState(0)
+    for window in (1, 3, 8, 40):
+        a, b = ReplayIndex(window), ReplayIndex(window)
+        ida, idb = {}, {}
+        g0 = 0
+        for _ in range(6):
+            lengths = rs.randint(1, 8, size=int(rs.randint(1, 12)))
+            da = a.save_games(lengths, 0)
+            for g, row in enumerate(da):
+                for m, s in enumerate(row):
+                    if s >= 0:
+                        ida[int(s)] = (g0 + g, m)
+            for g, n in enumerate(lengths):
+                for m, s in enumerate(b.save_games([n], 0)[0]):
+                    idb[int(s)] = (g0 + g, m)
+            g0 += len(lengths)
+            assert [ida[int(s)] for s in a.seq] == [idb[int(s)] for s in b.seq]
+            assert (a.n_games, a.full) == (b.n_games, b.full)
+
+
+def _round_worker(rank, world, port, ret):
+    """One self-play round on two ranks as bench.py --gpus 2 runs it, with CPU stand-ins for the engines: weights handed
+    over by one broadcast, games sharded by rank (disjoint seeds), rank-DEPENDENT game lengths, one gather, replay buffer
+    order on rank 0."""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    from nuzero_amd import dist as nzdist
+    from nuzero_amd.replay_device import ReplayIndex
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = synthetic_recurrent_net_weights(7, 2, 1, 16, 2, True) if rank == 0 else None
+        got = nzdist.broadcast_weights(w, src=0)
+        want = synthetic_recurrent_net_weights(7, 2, 1, 16, 2, True)
+        ok = list(got) == list(want) and all(np.array_equal(got[k].numpy(), want[k]) for k in want)
+        G, T = 6, 9
+        seed0 = nzdist.shard_seeds(1000, G, rank)
+        seeds = [seed0 + g for g in range(G)]
+        rs = np.random.RandomState(seed0)
+        lengths = rs.randint(5 + 2 * rank, 8 + 2 * rank, size=G).astype(np.int32)      # rank 1 plays longer games
+        p = _payload(rank, G, T)
+        p["lengths"] = torch.from_numpy(lengths)
+        p["states"][:, :, 0, 0, 0] = torch.tensor(seeds, dtype=torch.float32)[:, None]   # tag every position with its seed
+        out = nzdist.gather_payload(p, world, rank, dst=0)
+        all_seeds = [None] * world
+        td.all_gather_object(all_seeds, seeds)
+        flat = [s for part in all_seeds for s in part]
+        ok = ok and sorted(flat) == list(range(1000, 1000 + world * G)) and len(set(flat)) == world * G
+        if rank == 0:
+            tags = out["states"][:, 0, 0, 0, 0].tolist()
+            ok = ok and tags == [float(s) for s in flat]                                # rank-major order
+            idx = ReplayIndex(window_size=100)
+            dst = idx.save_games(out["lengths"].numpy(), 0)
+            ok = ok and len(idx) == int(out["lengths"].sum()) and (dst >= 0).sum(1).tolist() == out["lengths"].tolist()
+            ok = ok and out["lengths"][G:].float().mean() > out["lengths"][:G].float().mean()
+            ret["ok"] = bool(ok)
+        else:
+            ret["ok1"] = bool(ok) and out is None
+    finally:
+        td.destroy_process_group()
+
+
+def test_round_on_two_ranks_gloo():
+    """Weights broadcast + sharded seeds + ragged gather + replay order, world size 2 on CPU (the N > 1 path of bench.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_round_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get("ok") is True and ret.get("ok1") is True
+
+
+def test_broadcast_weights_single_process():
+    from nuzero_amd import dist as nzdist
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    w = synthetic_recurrent_net_weights(3, 2, 1, 16, 2, True)
+    got = nzdist.broadcast_weights(w)
+    assert list(got) == list(w) and all(np.array_equal(got[k].numpy(), w[k]) for k in w)
