@@ -37,8 +37,8 @@ class ReplayIndex:
 
     def save_games(self, lengths, game_index):
         """A batch of finished games, saved one after the other (save_game per game, in order).  Returns the physical
-        slot of every position, int64 [G, max(lengths)], -1 where a game has no such move (or where the position is
-        evicted again before the batch ends: a batch larger than the whole buffer)."""
+        slot of every position, int64 [G, max(lengths)], -1 where a game has no such move or where the position is
+        evicted again before the batch ends (the writes of one batch may then run in any order)."""
         lengths = np.asarray(lengths, np.int64)
         G = len(lengths)
         T = int(lengths.max()) if G else 0
@@ -62,10 +62,17 @@ class ReplayIndex:
             n = len(self.seq)
             P = int(lengths[k0:].sum())
             j = np.arange(P, dtype=np.int64)
-            slots = self.seq[j % n]
-            slots[j < P - n] = -1                     # overwritten again within this batch
-            dst[k0:][valid[k0:]] = slots
+            dst[k0:][valid[k0:]] = self.seq[j % n]
             self.seq = np.roll(self.seq, -(P % n))
+            # a position evicted before the batch ends (it was saved earlier in this same batch) is never stored: of
+            # the rows that name the same slot only the last one, in save order, keeps it
+            flat = dst.reshape(-1)
+            rows = np.nonzero(flat >= 0)[0]
+            _, last_from_end = np.unique(flat[rows][::-1], return_index=True)
+            keep = rows[len(rows) - 1 - last_from_end]
+            gone = np.ones(len(flat), bool)
+            gone[keep] = False
+            flat[gone] = -1
         if self.capacity is not None and len(self.seq) > self.capacity:
             raise ValueError(f"replay buffer holds {len(self.seq)} positions, capacity is {self.capacity}")
         if len(self.slot_game_index) < len(self.seq):
