@@ -372,6 +372,10 @@ nz_status nz_boardnet_forward_rows(nz_boardnet* h, int32_t n, const int32_t* n_d
                                    float* value_dev, void* stream);
 /* algorithmic FLOPs of one position (taps that fall off the board are not counted) */
 int64_t nz_boardnet_flops(const nz_boardnet* h);
+/* Narrow nets on small boards run all layers, the softmax and the value in ONE launch with the activations in LDS
+ * (when a workgroup's share of max_batch fits; same floats as the per-layer kernels).  enable: 1 / 0 switch it on /
+ * off (the A/B of the parity test), -1 leaves it; *available (may be NULL): whether the one-launch form was built. */
+nz_status nz_boardnet_fused(nz_boardnet* h, int32_t enable, int32_t* available);
 nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* policy_channels, int32_t* rows,
                            int32_t* cols, int32_t* max_batch);
 

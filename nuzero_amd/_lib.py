@@ -119,6 +119,7 @@ SIGNATURES = {
     "nz_boardnet_forward_rows": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_boardnet_flops": (c_int64, [c_void_p]),
     "nz_boardnet_dims": (c_int32, [c_void_p] + [POINTER(c_int32)] * 5),
+    "nz_boardnet_fused": (c_int32, [c_void_p, c_int32, POINTER(c_int32)]),
     "nz_scs_search_play": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_play_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "nz_scs_search_waves": (c_int32, [c_void_p, POINTER(c_int64)]),

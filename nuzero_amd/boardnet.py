@@ -58,6 +58,13 @@ class BoardNet:
         ptrs = (c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         self._check(lib.nz_boardnet_set_weights(self._h, ptrs, len(tensors), int(recurrent_iterations)))
 
+    def fused(self, enable=None):
+        """Whether the one-launch form of the network (all layers in LDS) exists for this net / board / max_batch;
+        `enable` = True / False switches its use on or off (both forms give the same floats)."""
+        avail = ctypes.c_int32(0)
+        self._check(lib.nz_boardnet_fused(self._h, -1 if enable is None else int(bool(enable)), byref(avail)))
+        return bool(avail.value)
+
     @property
     def flops_per_position(self):
         return int(lib.nz_boardnet_flops(self._h))

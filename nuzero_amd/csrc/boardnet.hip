@@ -456,6 +456,165 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
   if (lane == 0) value[n] = tanhf(s / (float)hw);
 }
 
+
+// ---- the whole network in ONE launch (narrow nets on small boards) ---------------------------------------------
+// A simulation wave of SCS self-play evaluates a few hundred leaves with a 32-filter network: one launch per layer
+// is 15 launches of ~10 us with the chip mostly idle.  Here one workgroup runs ALL layers for its share of the
+// positions (P = ceil(leaves / workgroups) of them; the leaf count is read from device memory), activations in LDS:
+//   * rows are (position, cell) pairs, row = local position * H*W + cell; an MFMA tile is 16 consecutive rows, so a
+//     conv tap is a per-lane row shift (same position, neighbouring cell) with a per-lane on-board test -- off-board
+//     taps contribute zero operands (the per-layer kernel skips them tile-wide; adding a zero product is exact, so the
+//     two kernels give the same floats);
+//   * same arithmetic and the same packed weights as conv_kernel: v_mfma_f32_16x16x4_f32, K order = tap, channel group;
+//   * the (output row tile, 16-channel column tile) jobs of a layer are dealt to the four wavefronts, one barrier
+//     per layer; the weight stream comes from L2 (every workgroup reads the same ~0.5 MB);
+//   * the softmax over all logits and the value's mean + tanh (finalize_kernel) run at the end, one wavefront per
+//     position, from LDS.
+constexpr int FUSED_MAX_OPS = 176;
+constexpr int FUSED_BUFFERS = 8;
+constexpr int FUSED_PAD = 4;               // floats added to every LDS row: spreads the 16 rows of a tile over the banks
+struct FusedOp {
+  int32_t src0, src1, res, dst;            // LDS buffer ids (-1: none)
+  int32_t kg0, kg1, ntiles, act;           // 16-channel groups of each source, 16-channel output tiles
+  const float* w;                          // packed weights (PackedConv::dev)
+};
+struct FusedProgram {
+  int32_t n_ops, hw, h, wd, policy_buf, value_buf, planes, hex;
+  int32_t buf_off[FUSED_BUFFERS];          // float offset of each buffer in LDS
+  int32_t buf_cs[FUSED_BUFFERS];           // floats per row (channels + FUSED_PAD)
+  FusedOp ops[FUSED_MAX_OPS];
+};
+
+template <bool HEX>
+__global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __restrict__ prog, const float* __restrict__ in_rows,
+                                                        int in_channels, const int32_t* __restrict__ n_dev, int n_host,
+                                                        float* __restrict__ logits, float* __restrict__ probs,
+                                                        float* __restrict__ value) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_pos = n_dev ? *n_dev : n_host;
+  const int P = (n_pos + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p0 = blockIdx.x * P;
+  if (p0 >= n_pos) return;                                  // uniform per workgroup
+  const int np = min(P, n_pos - p0);
+  const int hw = prog->hw, H = prog->h, Wd = prog->wd;
+  const int rows = np * hw, row_tiles = (rows + 15) >> 4;
+
+  {   // this workgroup's input rows -> LDS buffer 0 (global row of (position n, cell c): ((n >> 4) * hw + c) * 16 + (n & 15))
+    const int cs = prog->buf_cs[0];
+    float* dst = lds + prog->buf_off[0];
+    const int chunks = in_channels >> 2;                    // 16-byte pieces per row
+    for (int i = tid; i < rows * chunks; i += 256) {
+      const int r = i / chunks, c4 = (i - r * chunks) << 2;
+      const int pl = r / hw, cell = r - pl * hw, n = p0 + pl;
+      const size_t grow = ((size_t)(n >> 4) * hw + cell) * 16 + (n & 15);
+      *reinterpret_cast<f32x4*>(dst + r * cs + c4) = *reinterpret_cast<const f32x4*>(in_rows + grow * in_channels + c4);
+    }
+  }
+  __syncthreads();
+
+  constexpr int ntaps = HEX ? 7 : 9;
+  constexpr int DEPTH = 4;
+  const int q4 = (lane >> 4) * 4;
+  for (int o = 0; o < prog->n_ops; ++o) {
+    const FusedOp op = prog->ops[o];
+    const float* s0 = lds + prog->buf_off[op.src0];
+    const int cs0 = prog->buf_cs[op.src0];
+    const float* s1 = op.src1 >= 0 ? lds + prog->buf_off[op.src1] : s0;
+    const int cs1 = op.src1 >= 0 ? prog->buf_cs[op.src1] : cs0;
+    float* dst = lds + prog->buf_off[op.dst];
+    const int csd = prog->buf_cs[op.dst];
+    const float* res = op.res >= 0 ? lds + prog->buf_off[op.res] : nullptr;
+    const int csr = op.res >= 0 ? prog->buf_cs[op.res] : 0;
+    const int kg0 = op.kg0, kgt = op.kg0 + op.kg1;
+    const size_t tile_stride = (size_t)(ntaps + 1) * kgt * 256;
+    const int n_jobs = row_tiles * op.ntiles;
+    for (int job = wave; job < n_jobs; job += 4) {
+      const int rt = job / op.ntiles, ct = job - rt * op.ntiles;
+      const int row = rt * 16 + (lane & 15);
+      const bool row_ok = row < rows;
+      const int pl = row / hw, cell = row - pl * hw;
+      const int cy = cell / Wd, cx = cell - cy * Wd;
+      auto tap_dy = [&](int tap) { return HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1; };
+      auto tap_dx = [&](int tap) { return HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1; };
+      const float* wbase = op.w + (size_t)ct * tile_stride + lane * 4;
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 a[DEPTH], b[DEPTH];
+      int tap = 0, kg = 0;
+      auto issue = [&](int d) {
+        a[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tap < ntaps) {
+          const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
+          if (row_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd) {
+            const int srow = row + tap_dy(tap) * Wd + tap_dx(tap);
+            a[d] = kg < kg0 ? *reinterpret_cast<const f32x4*>(s0 + srow * cs0 + kg * 16 + q4)
+                            : *reinterpret_cast<const f32x4*>(s1 + srow * cs1 + (kg - kg0) * 16 + q4);
+          }
+        }
+        b[d] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)tap * kgt + kg) * 256);   // tap == ntaps: the zero block
+        if (++kg == kgt) {
+          kg = 0;
+          if (tap < ntaps) ++tap;
+        }
+      };
+      const int total = ntaps * kgt, rounds = (total + DEPTH - 1) / DEPTH;
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) issue(d);
+      for (int r = 0; r < rounds; ++r) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j], b[d][j], acc, 0, 0, 0);
+          issue(d);
+        }
+      }
+      const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = rt * 16 + r4 + r;
+        if (orow < rows) {
+          float v = acc[r];
+          if (res) v += res[orow * csr + col];
+          dst[orow * csd + col] = activate(v, op.act);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // softmax over ALL logits (Explorer.py:159), value = tanh(mean) (blocks.py:82-84): finalize_kernel's arithmetic
+  const float* pol = lds + prog->buf_off[prog->policy_buf];
+  const int pp = prog->buf_cs[prog->policy_buf];
+  const float* val = lds + prog->buf_off[prog->value_buf];
+  const int vp = prog->buf_cs[prog->value_buf];
+  const int A = prog->planes * hw;
+  for (int pl = wave; pl < np; pl += 4) {
+    const size_t n = (size_t)(p0 + pl);
+    float mx = -INFINITY;
+    for (int i = lane; i < A; i += 64) {
+      const float v = pol[(pl * hw + i % hw) * pp + i / hw];
+      if (logits) logits[n * A + i] = v;
+      mx = fmaxf(mx, v);
+    }
+    for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w));
+    if (probs) {
+      float sum = 0.f;
+      for (int i = lane; i < A; i += 64) {
+        const float e = expf(pol[(pl * hw + i % hw) * pp + i / hw] - mx);
+        probs[n * A + i] = e;
+        sum += e;
+      }
+      for (int w = 32; w; w >>= 1) sum += __shfl_xor(sum, w);
+      for (int i = lane; i < A; i += 64) probs[n * A + i] /= sum;
+    }
+    float sv = 0.f;
+    for (int c = lane; c < hw; c += 64) sv += val[(pl * hw + c) * vp];
+    for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w);
+    if (lane == 0) value[n] = tanhf(sv / (float)hw);
+  }
+}
+
 struct ConvOp {
   int src0, src1, res, dst;     // buffer ids (-1: none)
   int weight;                   // index into packed weights
@@ -483,6 +642,11 @@ struct nz_boardnet {
   int policy_buf = -1, value_buf = -1;
   bool ready = false;
   int64_t flops = 0;
+  // one-launch form (fused_net_kernel), built by set_weights when the activations of a workgroup's share fit in LDS
+  FusedProgram* fused_dev = nullptr;
+  bool use_fused = true;
+  int fused_grid = 0;
+  size_t fused_lds_bytes = 0;
   std::string error;
 };
 
@@ -656,6 +820,64 @@ void dispatch_conv(const ConvArgs& a, int ntiles, hipStream_t s) {
 }
 }  // namespace
 
+
+namespace {
+// The one-launch program for fused_net_kernel, when a workgroup's share of the largest batch fits in LDS: the ops of
+// forward_impl with LDS buffers instead of HBM ones.  The value head's two buffers reuse the two trunk buffers that are
+// free once the trunk is done (`trunk_out` holds its output).
+void build_fused(nz_boardnet* h, int trunk_out) {
+  static const int force = getenv("NZ_BOARDNET_FUSED") ? atoi(getenv("NZ_BOARDNET_FUSED")) : -1;   // tuning experiments
+  if (force == 0 || (int)h->ops.size() > FUSED_MAX_OPS) return;
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || n_cu <= 0) return;
+  const int grid = h->max_batch < n_cu ? h->max_batch : n_cu;
+  const int p_max = (h->max_batch + grid - 1) / grid;
+  const int rows_max = (p_max * h->hw + 15) / 16 * 16;
+  int alias[FUSED_BUFFERS] = {0, 1, 2, 3, 4, 5, 0, 0};
+  int free_ids[2], nf = 0;
+  for (int b = 1; b <= 3; ++b)
+    if (b != trunk_out && nf < 2) free_ids[nf++] = b;
+  alias[6] = free_ids[0]; alias[7] = free_ids[1];
+  FusedProgram pg;
+  memset(&pg, 0, sizeof(pg));
+  size_t off = 0;
+  for (int b = 0; b < 6; ++b) {
+    pg.buf_off[b] = (int32_t)off;
+    pg.buf_cs[b] = h->buffer_channels[b] + FUSED_PAD;
+    off += (size_t)rows_max * pg.buf_cs[b];
+  }
+  for (int b = 6; b < 8; ++b) {
+    if (h->buffer_channels[b] > h->buffer_channels[alias[b]]) return;      // cannot happen: the value head narrows
+    pg.buf_off[b] = pg.buf_off[alias[b]];
+    pg.buf_cs[b] = pg.buf_cs[alias[b]];
+  }
+  const size_t bytes = off * sizeof(float);
+  if (bytes > 156 * 1024) return;                      // 160 KB of LDS per CU
+  pg.n_ops = (int32_t)h->ops.size();
+  pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
+  pg.policy_buf = h->policy_buf; pg.value_buf = h->value_buf;
+  pg.planes = h->net.policy_channels; pg.hex = h->net.hex ? 1 : 0;
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const ConvOp& op = h->ops[i];
+    const PackedConv& pc = h->convs[i];
+    FusedOp& f = pg.ops[i];
+    f.src0 = op.src0; f.src1 = op.src1; f.res = op.res; f.dst = op.dst;
+    f.kg0 = pc.c0p / 16; f.kg1 = op.src1 >= 0 ? pc.c1p / 16 : 0;
+    f.ntiles = pc.coutp / 16; f.act = op.act; f.w = pc.dev;
+  }
+  const hipError_t e = h->net.hex
+      ? hipFuncSetAttribute((const void*)fused_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+      : hipFuncSetAttribute((const void*)fused_net_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return; }
+  FusedProgram* dev = nullptr;
+  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return;
+  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return; }
+  h->fused_dev = dev;
+  h->fused_grid = grid;
+  h->fused_lds_bytes = bytes;
+}
+}  // namespace
+
 extern "C" {
 
 const char* nz_boardnet_last_error(const nz_boardnet* h) { return h ? h->error.c_str() : g_err.c_str(); }
@@ -666,6 +888,7 @@ void nz_boardnet_destroy(nz_boardnet* h) {
   (void)hipDeviceSynchronize();
   for (float* b : h->buffers) (void)hipFree(b);
   for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
+  if (h->fused_dev) (void)hipFree(h->fused_dev);
   delete h;
 }
 
@@ -716,6 +939,7 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   B_HIP(h, hipDeviceSynchronize());
   for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
   h->convs.clear(); h->ops.clear(); h->flops = 0; h->ready = false;
+  if (h->fused_dev) { (void)hipFree(h->fused_dev); h->fused_dev = nullptr; }
   const nz_net_desc& nd = h->net;
   const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
   const int vact = nd.value_activation == NZ_ACT_RELU ? 1 : 2;
@@ -780,11 +1004,19 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   }
   if (!ok) return bfail(h, NZ_ERR_HIP, "weight upload failed");
   h->policy_buf = 5; h->value_buf = vsrc;
+  build_fused(h, cur);
   h->ready = true;
   return NZ_OK;
 }
 
 int64_t nz_boardnet_flops(const nz_boardnet* h) { return h ? h->flops : 0; }
+
+nz_status nz_boardnet_fused(nz_boardnet* h, int32_t enable, int32_t* available) {
+  if (!h) return NZ_ERR_ARG;
+  if (enable >= 0) h->use_fused = enable != 0;
+  if (available) *available = h->fused_dev != nullptr ? 1 : 0;
+  return NZ_OK;
+}
 
 nz_status nz_boardnet_dims(const nz_boardnet* h, int32_t* in_channels, int32_t* policy_channels, int32_t* rows,
                            int32_t* cols, int32_t* max_batch) {
@@ -810,6 +1042,16 @@ static nz_status forward_impl(nz_boardnet* h, const float* images_dev, int32_t n
   if (images_dev != nullptr)        // else: the caller filled the input rows itself (nz_boardnet_input_rows)
     hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
                        h->net.in_channels, h->inp, h->hw);
+  if (h->fused_dev != nullptr && h->use_fused) {    // every layer, the softmax and the value in one launch (activations in LDS)
+    if (h->net.hex)
+      hipLaunchKernelGGL(fused_net_kernel<true>, dim3(h->fused_grid), dim3(256), h->fused_lds_bytes, s, h->fused_dev,
+                         h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
+    else
+      hipLaunchKernelGGL(fused_net_kernel<false>, dim3(h->fused_grid), dim3(256), h->fused_lds_bytes, s, h->fused_dev,
+                         h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
+    B_HIP(h, hipGetLastError());
+    return NZ_OK;
+  }
   for (const ConvOp& op : h->ops) {
     const PackedConv& pc = h->convs[&op - h->ops.data()];
     ConvArgs a;

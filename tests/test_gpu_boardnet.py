@@ -247,3 +247,53 @@ def test_wide_layers_equal_the_oracle(arch, cin, planes, rows, cols, width, dept
     p = p.reshape(n, -1)
     _check(probs.cpu().numpy(), value.cpu().numpy(), logits.cpu().numpy(), softmax(p, axis=1), v.reshape(-1), p)
     net.close()
+
+
+@pytest.mark.parametrize("arch,hexnet,rows,cols,width,depth,n", [
+    ("convnet", False, 5, 5, 32, 8, 1024), ("convnet", True, 5, 5, 32, 8, 333), ("resnet", False, 5, 5, 32, 2, 37),
+    ("recurrent", False, 5, 5, 32, 2, 640), ("convnet", False, 10, 10, 32, 3, 70), ("resnet", False, 6, 5, 48, 2, 100)])
+def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, cols, width, depth, n):
+    """fused_net_kernel (all layers + softmax + value in one launch, activations in LDS, rows = (position, cell)) against
+    the per-layer kernels: the SAME floats (same MFMA, same K order; an off-board tap adds an exact zero), at ragged batch
+    sizes, with the batch size in device memory, for every architecture; and against the oracle within 1e-5."""
+    import torch
+    from scipy.special import softmax
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.weights import (synthetic_weights, hex_param_shapes, recurrent_net_param_shapes, resnet_param_shapes,
+                                    convnet_param_shapes)
+    from oracle.net import FeedForwardRef, HexNetRef, RecurrentNetRef
+    cin, planes, iters = 86, 21, 2
+    if arch == "recurrent":
+        shapes = recurrent_net_param_shapes(cin, planes, width, depth, True)
+    elif arch == "resnet":
+        shapes = resnet_param_shapes(cin, planes, width, depth)
+    else:
+        shapes = convnet_param_shapes(cin, planes, 3, width, depth)
+    w = synthetic_weights(23, hex_param_shapes(shapes) if hexnet else shapes, 2.0)
+    rs = np.random.RandomState(8)
+    x = (rs.random_sample((n, cin, rows, cols)) < 0.15).astype(np.float32)
+    x[:, -3:] = rs.random_sample((n, 3, rows, cols)).astype(np.float32)
+    net = BoardNet(arch, cin, planes, rows, cols, width=width, num_blocks=depth, recall=True, max_batch=n, hex=hexnet)
+    net.set_weights(w, iters)
+    assert net.fused()                                   # the one-launch form exists for these shapes
+    xd = torch.from_numpy(x).cuda()
+    pf, vf, lf = net.forward(xd, want_logits=True)
+    net.fused(False)
+    pu, vu, lu = net.forward(xd, want_logits=True)
+    assert torch.equal(lf, lu) and torch.equal(pf, pu) and torch.equal(vf, vu)
+    net.fused(True)
+    m = max(1, n // 3)                                   # live batch size on the device, smaller than the launch
+    n_dev = torch.tensor([m], dtype=torch.int32, device="cuda")
+    p2, v2 = net.forward(xd, n_dev=n_dev)
+    assert torch.equal(p2[:m], pf[:m]) and torch.equal(v2[:m], vf[:m])
+    k = min(n, 24)
+    if hexnet:
+        ref = HexNetRef(w, arch, depth, True, "tanh")
+    elif arch == "recurrent":
+        ref = RecurrentNetRef(w, cin, planes, width, depth, True, "tanh")
+    else:
+        ref = FeedForwardRef(w, arch, depth, "tanh")
+    p, v = ref.inference(x[:k], iters)
+    _check(pf[:k].cpu().numpy(), vf[:k].cpu().numpy(), lf[:k].cpu().numpy(), softmax(p.reshape(k, -1), axis=1), v.reshape(-1),
+           p.reshape(k, -1))
+    net.close()
