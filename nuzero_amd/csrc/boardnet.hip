@@ -466,12 +466,14 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
 //     taps contribute zero operands (the per-layer kernel skips them tile-wide; adding a zero product is exact, so the
 //     two kernels give the same floats);
 //   * same arithmetic and the same packed weights as conv_kernel: v_mfma_f32_16x16x4_f32, K order = tap, channel group;
-//   * the (output row tile, 16-channel column tile) jobs of a layer are dealt to the four wavefronts, one barrier
+//   * the (output row tile, 16-channel column tile) jobs of a layer are dealt to the sixteen wavefronts, one barrier
 //     per layer; the weight stream comes from L2 (every workgroup reads the same ~0.5 MB);
 //   * the softmax over all logits and the value's mean + tanh (finalize_kernel) run at the end, one wavefront per
 //     position, from LDS.
 constexpr int FUSED_MAX_OPS = 176;
 constexpr int FUSED_BUFFERS = 8;
+constexpr int FUSED_WAVES = 16;             // wavefronts per workgroup: a layer's jobs run side by side, four per SIMD
+constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int FUSED_PAD = 4;               // floats added to every LDS row: spreads the 16 rows of a tile over the banks
 struct FusedOp {
   int32_t src0, src1, res, dst;            // LDS buffer ids (-1: none)
@@ -486,7 +488,7 @@ struct FusedProgram {
 };
 
 template <bool HEX>
-__global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __restrict__ prog, const float* __restrict__ in_rows,
+__global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedProgram* __restrict__ prog, const float* __restrict__ in_rows,
                                                         int in_channels, const int32_t* __restrict__ n_dev, int n_host,
                                                         float* __restrict__ logits, float* __restrict__ probs,
                                                         float* __restrict__ value) {
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __re
     const int cs = prog->buf_cs[0];
     float* dst = lds + prog->buf_off[0];
     const int chunks = in_channels >> 2;                    // 16-byte pieces per row
-    for (int i = tid; i < rows * chunks; i += 256) {
+    for (int i = tid; i < rows * chunks; i += FUSED_THREADS) {
       const int r = i / chunks, c4 = (i - r * chunks) << 2;
       const int pl = r / hw, cell = r - pl * hw, n = p0 + pl;
       const size_t grow = ((size_t)(n >> 4) * hw + cell) * 16 + (n & 15);
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __re
   __syncthreads();
 
   constexpr int ntaps = HEX ? 7 : 9;
-  constexpr int DEPTH = 4;
+  constexpr int DEPTH = 6;
   const int q4 = (lane >> 4) * 4;
   for (int o = 0; o < prog->n_ops; ++o) {
     const FusedOp op = prog->ops[o];
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __re
     const int kg0 = op.kg0, kgt = op.kg0 + op.kg1;
     const size_t tile_stride = (size_t)(ntaps + 1) * kgt * 256;
     const int n_jobs = row_tiles * op.ntiles;
-    for (int job = wave; job < n_jobs; job += 4) {
+    for (int job = wave; job < n_jobs; job += FUSED_WAVES) {
       const int rt = job / op.ntiles, ct = job - rt * op.ntiles;
       const int row = rt * 16 + (lane & 15);
       const bool row_ok = row < rows;
@@ -542,17 +544,18 @@ __global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __re
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       f32x4 a[DEPTH], b[DEPTH];
       int tap = 0, kg = 0;
+      // branch-free: an off-board tap (or a padding row, or a step past the end of the K loop) reads a row that exists
+      // and turns it into zeros afterwards; the weights come through a global-address-space pointer (the pointer is
+      // loaded from memory: as a generic one it would be a FLAT load, which cannot be counted apart from the LDS reads)
+      typedef const __attribute__((address_space(1))) f32x4* gptr4;
       auto issue = [&](int d) {
-        a[d] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tap < ntaps) {
-          const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
-          if (row_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd) {
-            const int srow = row + tap_dy(tap) * Wd + tap_dx(tap);
-            a[d] = kg < kg0 ? *reinterpret_cast<const f32x4*>(s0 + srow * cs0 + kg * 16 + q4)
-                            : *reinterpret_cast<const f32x4*>(s1 + srow * cs1 + (kg - kg0) * 16 + q4);
-          }
-        }
-        b[d] = *reinterpret_cast<const f32x4*>(wbase + ((size_t)tap * kgt + kg) * 256);   // tap == ntaps: the zero block
+        const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
+        const bool on = row_ok && tap < ntaps && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd;
+        const int srow = on ? row + tap_dy(tap) * Wd + tap_dx(tap) : 0;
+        const float* sp = kg < kg0 ? s0 + srow * cs0 + kg * 16 + q4 : s1 + srow * cs1 + (kg - kg0) * 16 + q4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
+        a[d] = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        b[d] = *(gptr4)(wbase + ((size_t)tap * kgt + kg) * 256);   // tap == ntaps: the block of zeros
         if (++kg == kgt) {
           kg = 0;
           if (tap < ntaps) ++tap;
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(256) void fused_net_kernel(const FusedProgram* __re
   const float* val = lds + prog->buf_off[prog->value_buf];
   const int vp = prog->buf_cs[prog->value_buf];
   const int A = prog->planes * hw;
-  for (int pl = wave; pl < np; pl += 4) {
+  for (int pl = wave; pl < np; pl += FUSED_WAVES) {
     const size_t n = (size_t)(p0 + pl);
     float mx = -INFINITY;
     for (int i = lane; i < A; i += 64) {
@@ -1044,10 +1047,10 @@ static nz_status forward_impl(nz_boardnet* h, const float* images_dev, int32_t n
                        h->net.in_channels, h->inp, h->hw);
   if (h->fused_dev != nullptr && h->use_fused) {    // every layer, the softmax and the value in one launch (activations in LDS)
     if (h->net.hex)
-      hipLaunchKernelGGL(fused_net_kernel<true>, dim3(h->fused_grid), dim3(256), h->fused_lds_bytes, s, h->fused_dev,
+      hipLaunchKernelGGL(fused_net_kernel<true>, dim3(h->fused_grid), dim3(FUSED_THREADS), h->fused_lds_bytes, s, h->fused_dev,
                          h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
     else
-      hipLaunchKernelGGL(fused_net_kernel<false>, dim3(h->fused_grid), dim3(256), h->fused_lds_bytes, s, h->fused_dev,
+      hipLaunchKernelGGL(fused_net_kernel<false>, dim3(h->fused_grid), dim3(FUSED_THREADS), h->fused_lds_bytes, s, h->fused_dev,
                          h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
     B_HIP(h, hipGetLastError());
     return NZ_OK;

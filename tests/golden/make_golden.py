@@ -505,7 +505,34 @@ def gen_unit():
     return {k: len(v) for k, v in cases.items()}
 
 
+E2E_CASES = [
+    # name, net, config, seeds: the REAL network inside the genuine Explorer (no cache, no table)
+    ("e2e25_A", "A", cfg(25), list(range(800, 816))),
+    ("e2e100_A", "A", cfg(100), list(range(820, 836))),
+    ("e2e25_B", "B", cfg(25), list(range(840, 856))),
+    ("e2e100_B", "B", cfg(100), list(range(860, 876))),
+]
+
+
+def gen_e2e():
+    """SURVEY.md section 8c KAT 6: seeded self-play games with the real RecurrentNet(2,1,64,2) evaluated by the genuine
+    Explorer through Network_Manager.inference (Explorer.py:157-162), 2 recurrent iterations: per-move visit counts,
+    priors, value sums.  The device's network differs from torch's in the last float32 bits, so these games are
+    compared with an agreement rule (tests/test_gpu_parity.py::test_end_to_end_agreement_with_the_real_network)."""
+    out = {}
+    for name, net, config, seeds in E2E_CASES:
+        nm = build_ref_net(net)
+        out[name] = {"net": net, "config": config, "training": True,
+                     "games": [play_reference_game(config, True, s, nm, None) for s in seeds]}
+    with gzip.open(os.path.join(HERE, "e2e_kat.json.gz"), "wt") as f:
+        json.dump(out, f)
+    return {k: len(v["games"]) for k, v in out.items()}
+
+
 def main():
+    if "--only-e2e" in sys.argv:
+        print(json.dumps(gen_e2e(), indent=1))
+        return
     if "--only-nets2" in sys.argv:          # added later; leaves the other fixtures byte-identical
         print(json.dumps(gen_nets2(reachable()), indent=1))
         return
@@ -525,6 +552,7 @@ def main():
     meta["nets3"] = gen_nets3()
     meta["search"] = gen_search(codes, tables)
     meta["unit"] = gen_unit()
+    meta["e2e"] = gen_e2e()
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1)
     print(json.dumps(meta, indent=1))

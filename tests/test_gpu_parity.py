@@ -541,3 +541,62 @@ def test_gamer_and_inference_follow_in_place_weight_updates():
     for k in keys:
         assert np.array_equal(r1[k], r1b[k]), k
     g.engine.close(); fresh.engine.close()
+
+
+def test_end_to_end_agreement_with_the_real_network():
+    """SURVEY.md section 8c KAT 6: 64 self-play games the GENUINE reference played with the real RecurrentNet(2,1,64,2)
+    inside its Explorer (tests/golden/e2e_kat.json.gz: 25 and 100 simulations, the bench network A and the sharper B)
+    against the device playing the same seeds with its own fused network.  The tree arithmetic is exact and the
+    network agrees to 1e-5, but a last-bit difference in a prior can flip a near-tied PUCT argmax, after which the two
+    games are different games.  Reported and bounded here: the fraction of moves whose visit vectors are identical,
+    and -- on every move up to and including a game's first divergence -- priors within 1e-5 (north-star tolerance)
+    and value sums within 1e-5 per visit."""
+    import gzip
+    import json
+    import os
+    from conftest import GOLDEN
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    with gzip.open(os.path.join(GOLDEN, "e2e_kat.json.gz"), "rt") as f:
+        kat = json.load(f)
+    nets = {"A": (0, 64, 1.0), "B": (1, 64, 3.0)}
+    report = {}
+    for name, case in kat.items():
+        games = case["games"]
+        seed, width, gain = nets[case["net"]]
+        eng = _engine(case["config"], len(games), training=True)
+        eng.set_weights(synthetic_recurrent_net_weights(seed, 2, 1, width, 2, True, gain), width=width, recurrent_iterations=2)
+        eng.play_with_numpy_rng([g["seed"] for g in games])
+        r = eng.export(trace=True)
+        same_moves = total_moves = same_games = 0
+        worst_prior = worst_value = 0.0
+        for g, ref in enumerate(games):
+            diverged = False
+            for m, mv in enumerate(ref["moves"]):
+                total_moves += 1
+                if diverged:
+                    continue
+                acts = mv["child_actions"]
+                # up to the first divergence the two searches saw the same positions: floats must agree to tolerance
+                if r["n_children"][g, m] == len(acts):
+                    worst_prior = max(worst_prior, float(np.abs(r["child_prior"][g, m][acts] - np.array(mv["child_priors"])).max()))
+                    n = max(1, mv["root_visits"])
+                    worst_value = max(worst_value, abs(float(r["root_value_sum"][g, m]) - mv["root_value_sum"]) / n)
+                want = np.zeros(9, np.int64)
+                want[acts] = mv["child_visits"]
+                if np.array_equal(r["visits"][g, m], want) and r["actions"][g, m] == mv["action"]:
+                    same_moves += 1
+                else:
+                    diverged = True
+            if not diverged and r["lengths"][g] == ref["length"] and r["outcomes"][g] == ref["terminal_value"]:
+                same_games += 1
+        report[name] = {"identical_move_fraction": same_moves / total_moves, "identical_games": same_games,
+                        "games": len(games), "max_prior_diff": worst_prior, "max_value_diff_per_visit": worst_value}
+        eng.close()
+    print("end-to-end agreement with the reference's real-network games:", json.dumps(report))
+    for name, rep in report.items():
+        assert rep["max_prior_diff"] <= 1e-5 and rep["max_value_diff_per_visit"] <= 1e-5, (name, rep)
+        assert rep["identical_move_fraction"] >= 0.9, (name, rep)
+    out_dir = os.environ.get("NZ_REPORT_DIR")
+    if out_dir:
+        with open(os.path.join(out_dir, "e2e_agreement.json"), "w") as f:
+            json.dump(report, f, indent=1)
