@@ -28,6 +28,7 @@
 // Search/Explorer.py:158-162 (softmax over all logits, value .item()).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -479,13 +480,86 @@ struct FusedOp {
   int32_t src0, src1, res, dst;            // LDS buffer ids (-1: none)
   int32_t kg0, kg1, ntiles, act;           // 16-channel groups of each source, 16-channel output tiles
   const float* w;                          // packed weights (PackedConv::dev)
+  int32_t w_lds, pad;                      // 1: the layer's weights are staged in LDS (they fit the weight buffer)
 };
 struct FusedProgram {
   int32_t n_ops, hw, h, wd, policy_buf, value_buf, planes, hex;
+  int32_t zrow_off, wbuf_off;              // float offsets of the zero row and of the weight buffer in LDS
   int32_t buf_off[FUSED_BUFFERS];          // float offset of each buffer in LDS
   int32_t buf_cs[FUSED_BUFFERS];           // floats per row (channels + FUSED_PAD)
   FusedOp ops[FUSED_MAX_OPS];
 };
+
+
+constexpr int FUSED_ZROW = 256;            // floats of zeros in LDS: the operand row of a tap that falls off the board
+constexpr int FUSED_WREGS = 3;             // 16-byte pieces of the next layer's weights a thread carries
+typedef const __attribute__((address_space(1))) f32x4* gptr4;
+
+// A layer's weights [col tile][tap < NTAPS][kg][lane][4] (what conv_job reads from LDS) out of the packed stream
+// [col tile][NTAPS + 1][kg][lane][4]: piece i of 16 bytes, i = tid + 1024 j.
+template <int NTAPS>
+__device__ __forceinline__ void fetch_weights(const FusedOp& op, f32x4 (&wreg)[FUSED_WREGS], int tid) {
+  const int kgt = op.kg0 + op.kg1, per_tile = NTAPS * kgt * 64, total = op.ntiles * per_tile;
+#pragma unroll
+  for (int j = 0; j < FUSED_WREGS; ++j) {
+    const int i = tid + j * FUSED_THREADS;
+    if (i < total) {
+      const int ct = i / per_tile, within = i - ct * per_tile;
+      wreg[j] = *((gptr4)op.w + (size_t)ct * ((NTAPS + 1) * kgt * 64) + within);
+    }
+  }
+}
+template <int NTAPS>
+__device__ __forceinline__ void store_weights(const FusedOp& op, float* wbuf, const f32x4 (&wreg)[FUSED_WREGS], int tid) {
+  const int kgt = op.kg0 + op.kg1, total = op.ntiles * NTAPS * kgt * 64;
+#pragma unroll
+  for (int j = 0; j < FUSED_WREGS; ++j) {
+    const int i = tid + j * FUSED_THREADS;
+    if (i < total) *reinterpret_cast<f32x4*>(wbuf + (size_t)i * 4) = wreg[j];
+  }
+}
+template <int NTAPS>
+__device__ __forceinline__ void stage_weights(const FusedOp& op, float* wbuf, int tid, bool) {
+  f32x4 wreg[FUSED_WREGS];
+  fetch_weights<NTAPS>(op, wreg, tid);
+  store_weights<NTAPS>(op, wbuf, wreg, tid);
+}
+
+// One (row tile, column tile) job as straight-line code: NTAPS x KGT steps of four MFMAs, K order = tap, channel group
+// (conv_kernel's).  Every index is a compile-time constant; the A operands come from LDS (aoff[tap]: this lane's
+// operand row), the B operands from the LDS copy of the layer's weights (WLDS) or straight from the packed stream in L2.
+template <int NTAPS, int KGT, bool WLDS>
+__device__ __forceinline__ void conv_job(f32x4& acc, const float* __restrict__ lds, const int (&aoff)[NTAPS],
+                                         const float* __restrict__ wl, const float* __restrict__ wg) {
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll
+    for (int kg = 0; kg < KGT; ++kg) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(lds + aoff[tap] + kg * 16);
+      f32x4 b;
+      if constexpr (WLDS) b = *reinterpret_cast<const f32x4*>(wl + (tap * KGT + kg) * 256);
+      else b = *((gptr4)(wg + (tap * KGT + kg) * 256));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+  }
+}
+// any channel-group count, two K sources (the recall concatenation): taps unrolled, channel groups a run-time loop
+template <int NTAPS>
+__device__ __forceinline__ void conv_job_generic(f32x4& acc, const float* __restrict__ lds, const int (&aoff0)[NTAPS],
+                                                 const int (&aoff1)[NTAPS], int kg0, int kgt, const float* w) {
+  // `w`: LDS copy ([tap][kg] contiguous) or the packed stream (same order within a column tile)
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+    for (int kg = 0; kg < kgt; ++kg) {
+      const f32x4 a = kg < kg0 ? *reinterpret_cast<const f32x4*>(lds + aoff0[tap] + kg * 16)
+                               : *reinterpret_cast<const f32x4*>(lds + aoff1[tap] + (kg - kg0) * 16);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(w + (size_t)(tap * kgt + kg) * 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+    }
+  }
+}
 
 template <bool HEX>
 __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedProgram* __restrict__ prog, const float* __restrict__ in_rows,
@@ -517,14 +591,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
   __syncthreads();
 
   constexpr int ntaps = HEX ? 7 : 9;
-  constexpr int DEPTH = 6;
   const int q4 = (lane >> 4) * 4;
+  float* const wbuf = lds + prog->wbuf_off;                 // this layer's weights, when they fit (FusedOp::w_lds)
+  for (int i = tid; i < FUSED_ZROW; i += FUSED_THREADS) lds[prog->zrow_off + i] = 0.f;   // what an off-board tap reads
+  if (prog->n_ops > 0 && prog->ops[0].w_lds) stage_weights<ntaps>(prog->ops[0], wbuf, tid, true);
+  __syncthreads();
+
   for (int o = 0; o < prog->n_ops; ++o) {
     const FusedOp op = prog->ops[o];
-    const float* s0 = lds + prog->buf_off[op.src0];
-    const int cs0 = prog->buf_cs[op.src0];
-    const float* s1 = op.src1 >= 0 ? lds + prog->buf_off[op.src1] : s0;
-    const int cs1 = op.src1 >= 0 ? prog->buf_cs[op.src1] : cs0;
+    // the NEXT layer's weights start their way from L2 now and are parked in registers under this layer's MFMAs
+    const bool next_lds = o + 1 < prog->n_ops && prog->ops[o + 1].w_lds;
+    f32x4 wreg[FUSED_WREGS];
+    if (next_lds) fetch_weights<ntaps>(prog->ops[o + 1], wreg, tid);
+    const int off0 = prog->buf_off[op.src0], cs0 = prog->buf_cs[op.src0];
+    const int off1 = op.src1 >= 0 ? prog->buf_off[op.src1] : off0, cs1 = op.src1 >= 0 ? prog->buf_cs[op.src1] : cs0;
     float* dst = lds + prog->buf_off[op.dst];
     const int csd = prog->buf_cs[op.dst];
     const float* res = op.res >= 0 ? lds + prog->buf_off[op.res] : nullptr;
@@ -538,40 +618,27 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
       const bool row_ok = row < rows;
       const int pl = row / hw, cell = row - pl * hw;
       const int cy = cell / Wd, cx = cell - cy * Wd;
-      auto tap_dy = [&](int tap) { return HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1; };
-      auto tap_dx = [&](int tap) { return HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1; };
-      const float* wbase = op.w + (size_t)ct * tile_stride + lane * 4;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      f32x4 a[DEPTH], b[DEPTH];
-      int tap = 0, kg = 0;
-      // branch-free: an off-board tap (or a padding row, or a step past the end of the K loop) reads a row that exists
-      // and turns it into zeros afterwards; the weights come through a global-address-space pointer (the pointer is
-      // loaded from memory: as a generic one it would be a FLAT load, which cannot be counted apart from the LDS reads)
-      typedef const __attribute__((address_space(1))) f32x4* gptr4;
-      auto issue = [&](int d) {
-        const int y = cy + tap_dy(tap), x = cx + tap_dx(tap);
-        const bool on = row_ok && tap < ntaps && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)Wd;
-        const int srow = on ? row + tap_dy(tap) * Wd + tap_dx(tap) : 0;
-        const float* sp = kg < kg0 ? s0 + srow * cs0 + kg * 16 + q4 : s1 + srow * cs1 + (kg - kg0) * 16 + q4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sp);
-        a[d] = on ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        b[d] = *(gptr4)(wbase + ((size_t)tap * kgt + kg) * 256);   // tap == ntaps: the block of zeros
-        if (++kg == kgt) {
-          kg = 0;
-          if (tap < ntaps) ++tap;
-        }
-      };
-      const int total = ntaps * kgt, rounds = (total + DEPTH - 1) / DEPTH;
+      // per tap: where this lane's operand row starts in LDS (float index); off the board -> the row of zeros
+      int aoff0[ntaps], aoff1[ntaps];
 #pragma unroll
-      for (int d = 0; d < DEPTH; ++d) issue(d);
-      for (int r = 0; r < rounds; ++r) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[d][j], b[d][j], acc, 0, 0, 0);
-          issue(d);
-        }
+      for (int tap = 0; tap < ntaps; ++tap) {
+        const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+        const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+        const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+        const int srow = row + dy * Wd + dx;
+        aoff0[tap] = on ? off0 + srow * cs0 + q4 : prog->zrow_off + q4;
+        aoff1[tap] = on ? off1 + srow * cs1 + q4 : prog->zrow_off + q4;
       }
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wl = wbuf + (size_t)ct * (ntaps * kgt * 256) + lane * 4;        // LDS copy: [ct][tap][kg][lane][4]
+      const float* wg = op.w + (size_t)ct * tile_stride + lane * 4;                // packed stream in L2
+      if (op.src1 < 0 && op.w_lds && kgt == 2) conv_job<ntaps, 2, true>(acc, lds, aoff0, wl, wg);
+      else if (op.src1 < 0 && op.w_lds && kgt == 1) conv_job<ntaps, 1, true>(acc, lds, aoff0, wl, wg);
+      else if (op.src1 < 0 && op.w_lds && kgt == 3) conv_job<ntaps, 3, true>(acc, lds, aoff0, wl, wg);
+      else if (op.src1 < 0 && op.w_lds && kgt == 4) conv_job<ntaps, 4, true>(acc, lds, aoff0, wl, wg);
+      else if (op.src1 < 0 && kgt == 6) conv_job<ntaps, 6, false>(acc, lds, aoff0, wl, wg);
+      else if (op.src1 < 0 && kgt == 2) conv_job<ntaps, 2, false>(acc, lds, aoff0, wl, wg);
+      else conv_job_generic<ntaps>(acc, lds, aoff0, aoff1, kg0, kgt, op.w_lds ? wl : wg);
       const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -583,7 +650,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
         }
       }
     }
-    __syncthreads();
+    __syncthreads();                        // the layer's outputs are complete; nobody reads wbuf any more
+    if (next_lds) {
+      store_weights<ntaps>(prog->ops[o + 1], wbuf, wreg, tid);
+      __syncthreads();
+    }
   }
 
   // softmax over ALL logits (Explorer.py:159), value = tanh(mean) (blocks.py:82-84): finalize_kernel's arithmetic
@@ -836,30 +907,38 @@ void build_fused(nz_boardnet* h, int trunk_out) {
   const int grid = h->max_batch < n_cu ? h->max_batch : n_cu;
   const int p_max = (h->max_batch + grid - 1) / grid;
   const int rows_max = (p_max * h->hw + 15) / 16 * 16;
-  int alias[FUSED_BUFFERS] = {0, 1, 2, 3, 4, 5, 0, 0};
   int free_ids[2], nf = 0;
   for (int b = 1; b <= 3; ++b)
     if (b != trunk_out && nf < 2) free_ids[nf++] = b;
-  alias[6] = free_ids[0]; alias[7] = free_ids[1];
+  // the heads run after the trunk, policy first: its hidden layer and the value head's two buffers live in the two
+  // trunk buffers that are free by then (when they are wide enough); the logits keep their own buffer for the softmax
+  int alias[FUSED_BUFFERS] = {0, 1, 2, 3, 4, 5, free_ids[0], free_ids[1]};
+  if (h->buffer_channels[4] <= h->buffer_channels[free_ids[0]]) alias[4] = free_ids[0];
+  for (int b = 6; b < 8; ++b)
+    if (h->buffer_channels[b] > h->buffer_channels[alias[b]]) return;      // cannot happen: the value head narrows
   FusedProgram pg;
   memset(&pg, 0, sizeof(pg));
   size_t off = 0;
-  for (int b = 0; b < 6; ++b) {
+  pg.zrow_off = 0;
+  off += FUSED_ZROW;
+  for (int b = 0; b < FUSED_BUFFERS; ++b) {
+    if (alias[b] != b) continue;
     pg.buf_off[b] = (int32_t)off;
     pg.buf_cs[b] = h->buffer_channels[b] + FUSED_PAD;
     off += (size_t)rows_max * pg.buf_cs[b];
   }
-  for (int b = 6; b < 8; ++b) {
-    if (h->buffer_channels[b] > h->buffer_channels[alias[b]]) return;      // cannot happen: the value head narrows
-    pg.buf_off[b] = pg.buf_off[alias[b]];
-    pg.buf_cs[b] = pg.buf_cs[alias[b]];
-  }
-  const size_t bytes = off * sizeof(float);
-  if (bytes > 156 * 1024) return;                      // 160 KB of LDS per CU
+  for (int b = 0; b < FUSED_BUFFERS; ++b)
+    if (alias[b] != b) { pg.buf_off[b] = pg.buf_off[alias[b]]; pg.buf_cs[b] = pg.buf_cs[alias[b]]; }
+  const size_t budget = 156 * 1024 / sizeof(float);      // 160 KB of LDS per CU
+  if (off > budget) return;
   pg.n_ops = (int32_t)h->ops.size();
   pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
   pg.policy_buf = h->policy_buf; pg.value_buf = h->value_buf;
   pg.planes = h->net.policy_channels; pg.hex = h->net.hex ? 1 : 0;
+  const int ntaps = h->net.hex ? 7 : 9;
+  // layers whose weights fit in what is left of LDS (and in the registers that carry them there) are staged
+  const size_t w_cap = std::min(budget - off, (size_t)FUSED_WREGS * FUSED_THREADS * 4);
+  size_t wbuf = 0;
   for (size_t i = 0; i < h->ops.size(); ++i) {
     const ConvOp& op = h->ops[i];
     const PackedConv& pc = h->convs[i];
@@ -867,7 +946,13 @@ void build_fused(nz_boardnet* h, int trunk_out) {
     f.src0 = op.src0; f.src1 = op.src1; f.res = op.res; f.dst = op.dst;
     f.kg0 = pc.c0p / 16; f.kg1 = op.src1 >= 0 ? pc.c1p / 16 : 0;
     f.ntiles = pc.coutp / 16; f.act = op.act; f.w = pc.dev;
+    const size_t wf = (size_t)f.ntiles * ntaps * (f.kg0 + f.kg1) * 256;
+    f.w_lds = wf <= w_cap ? 1 : 0;
+    if (f.w_lds) wbuf = std::max(wbuf, wf);
   }
+  pg.wbuf_off = (int32_t)off;
+  off += wbuf;
+  const size_t bytes = off * sizeof(float);
   const hipError_t e = h->net.hex
       ? hipFuncSetAttribute((const void*)fused_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
       : hipFuncSetAttribute((const void*)fused_net_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
