@@ -394,6 +394,10 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
 /* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
  * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
 nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);
+/* What the per-move records hold, bounded from the game description at create (the reference itself has no limits,
+ * SCS_Game.py:395-484): decisions per game (= the M of nz_scs_search_export's [G, M] / [G, M, C] arrays) and children
+ * per node (= C, a multiple of 64, at most 256; a description that allows more is rejected by nz_scs_search_create). */
+nz_status nz_scs_search_limits(const nz_scs_search* h, int32_t* max_moves, int32_t* max_children);
 /* simulation waves (kernel rounds) the last nz_scs_search_play took */
 nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves);
 

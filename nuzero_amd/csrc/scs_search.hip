@@ -30,8 +30,10 @@ using namespace nz;
 
 namespace {
 
-constexpr int MAXC = 64;          // children per node = lanes of a wavefront
-constexpr int MAX_MOVES = 256;    // decisions per game that can be recorded
+// Children per node and decisions per game are bounded from the game description when the engine is created
+// (nz_scs_search_create: `scs_limits`), not by constants: a wavefront handles a node's children in chunks of 64 lanes.
+constexpr int MAXC_CHUNKS = 4;                 // chunks of 64 children a node may have
+constexpr int MAXC_LIMIT = 64 * MAXC_CHUNKS;   // 256: more legal actions than that in one position are rejected at create
 constexpr int MAX_ACTIONS = 21 * SCS_MAX_TILES;
 constexpr int MASK_WORDS = (MAX_ACTIONS + 31) / 32;
 
@@ -76,17 +78,19 @@ struct SearchParams {
   int32_t pw_blocks;
   uint16_t pw_hi[48], pw_be[48];
   uint8_t pw_merge[48];
+  int32_t maxc;            // children per node the records hold (a multiple of 64, <= MAXC_LIMIT)
+  int32_t max_moves;       // decisions per game the records hold
   int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
   int32_t image_row_stride; // > 0: leaf images are written as input rows of a board net (floats per row), else NCHW
   int32_t* error_flag;
   int64_t* counters;       // [16] simulations, expansions; [2..7] shader ticks per phase of the NZ_SCS_STAMPS diagnostic build
-  // records [G][MAX_MOVES]...
+  // records [G][max_moves]...
   int32_t* rec_action;
   int32_t* rec_tree_size;
   int32_t* rec_children;
   double* rec_bias;
   double* rec_root_value_sum;
-  int32_t* rec_child_action;   // [G][MAX_MOVES][MAXC]
+  int32_t* rec_child_action;   // [G][max_moves][maxc]
   int32_t* rec_child_visit;
   double* rec_child_prior;
   double* rec_child_value_sum;
@@ -116,12 +120,20 @@ __device__ __forceinline__ double child_score(const SearchParams& p, const SNode
 // is zero except at k sorted positions; adding a zero is exact, so only the non-zero entries and numpy's block
 // structure matter.  Wave-uniform: lane i holds the i-th non-zero entry (idx ascending, val), every lane walks the
 // block program of SearchParams (built on the host) with the entries broadcast by v_readlane -- no memory accesses.
-__device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, int idx, float val, int k) {
+// Entry j lives in lane j & 63 of register j >> 6 (up to MAXC_CHUNKS registers per lane).
+__device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, const int (&idx)[MAXC_CHUNKS],
+                                                        const float (&val)[MAXC_CHUNKS], int k) {
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f, st4 = 0.f, st5 = 0.f, st6 = 0.f, st7 = 0.f;   // block-sum stack
   int sp = 0, i = 0, lo = 0;
-  auto entry_idx = [&](int j) { return __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(j)); };
+  auto entry_idx = [&](int j) {
+    const int c = __builtin_amdgcn_readfirstlane(j >> 6), l = __builtin_amdgcn_readfirstlane(j & 63);
+    const int r = c == 0 ? idx[0] : c == 1 ? idx[1] : c == 2 ? idx[2] : idx[3];
+    return __builtin_amdgcn_readlane(r, l);
+  };
   auto entry_val = [&](int j) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, val), __builtin_amdgcn_readfirstlane(j)));
+    const int c = __builtin_amdgcn_readfirstlane(j >> 6), l = __builtin_amdgcn_readfirstlane(j & 63);
+    const float r = c == 0 ? val[0] : c == 1 ? val[1] : c == 2 ? val[2] : val[3];
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), l));
   };
   for (int b = 0; b < p.pw_blocks; ++b) {
     const int hi = p.pw_hi[b], be = p.pw_be[b];
@@ -199,10 +211,10 @@ __global__ void search_reset_kernel(SearchParams p) {
   p.sims_left[g] = 0;
   p.pending[g] = -1;
   p.path_len[g] = 0;
-  for (int m = 0; m < MAX_MOVES; ++m) {
-    p.rec_action[g * MAX_MOVES + m] = -1;
-    p.rec_children[g * MAX_MOVES + m] = 0;
-    p.rec_tree_size[g * MAX_MOVES + m] = 0;
+  for (int m = 0; m < p.max_moves; ++m) {
+    p.rec_action[(size_t)g * p.max_moves + m] = -1;
+    p.rec_children[(size_t)g * p.max_moves + m] = 0;
+    p.rec_tree_size[(size_t)g * p.max_moves + m] = 0;
   }
 }
 
@@ -220,9 +232,9 @@ __global__ void begin_move_kernel(SearchParams p, const double* __restrict__ noi
   if (p.real[g].terminal) return;
   SNode* nodes = arena(p, g);
   const SNode& root = nodes[p.root[g]];
-  if (p.training && lane < root.n_children) {
-    SNode& c = nodes[root.child_base + lane];
-    const double n = noise[(size_t)g * MAXC + lane];
+  for (int j = lane; p.training && j < root.n_children; j += 64) {
+    SNode& c = nodes[root.child_base + j];
+    const double n = noise[(size_t)g * p.maxc + j];
     double a;
     if (c.prior_f64) a = c.prior * p.one_minus_frac;
     else a = (double)((float)c.prior * (float)p.one_minus_frac);
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   __shared__ ScsRules R;
   __shared__ ScsState sc;
   __shared__ uint32_t smask[MASK_WORDS];
-  __shared__ int sidx[MAXC];
+  __shared__ int sidx[MAXC_LIMIT];
   const int g = blockIdx.x;
   const int lane = lane_id();
 #ifdef NZ_SCS_STAMPS     // diagnostic build: where a game's wave time goes (nz_scs_search_phase_ticks)
@@ -302,30 +314,41 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       while (bits) {
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
-        if (off < MAXC) sidx[off] = (w * 64 + lane) * 32 + b;
+        if (off < MAXC_LIMIT) sidx[off] = (w * 64 + lane) * 32 + b;
         ++off;
       }
       k += __shfl(inc, 63, 64);
     }
     const int base = base_in;
-    const bool overflow = k > MAXC;
+    const bool overflow = k > p.maxc;
     if (overflow || base + k > p.half_cap) {
       if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
     } else {
       __syncthreads();
-      const int my_idx = lane < k ? sidx[lane] : 0x7fffffff;
-      float my_val = lane < k ? probs[(size_t)slot * A + my_idx] : 0.0f;
+      int my_idx[MAXC_CHUNKS];                // child 64 c + lane: its action and its masked probability
+      float my_val[MAXC_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        my_idx[c] = j < k ? sidx[j] : 0x7fffffff;
+        my_val[c] = j < k ? probs[(size_t)slot * A + my_idx[c]] : 0.0f;
+      }
       float total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
       if (total == 0.0f) {                  // probs += mask (Explorer.py:171-173)
-        my_val = my_val + 1.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC_CHUNKS; ++c) my_val[c] = my_val[c] + 1.0f;
         total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
       }
-      if (lane < k) {
-        SNode c;
-        c.prior = (double)(my_val / total);
-        c.value_sum = 0.0; c.visit = 0; c.child_base = 0; c.n_children = 0; c.action = (uint16_t)my_idx;
-        c.to_play = -1; c.prior_f64 = 0; c.terminal = 0; c.pad = 0;
-        nodes[base + lane] = c;
+#pragma unroll
+      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        if (j < k) {
+          SNode n;
+          n.prior = (double)(my_val[c] / total);
+          n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = (uint16_t)my_idx[c];
+          n.to_play = -1; n.prior_f64 = 0; n.terminal = 0; n.pad = 0;
+          nodes[base + j] = n;
+        }
       }
       if (lane == 0) {
         nodes[leaf].child_base = base;
@@ -385,10 +408,11 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       const bool negate = parent.to_play == p.negate_player;
       double score = -INFINITY;
       int key = -1;
-      if (lane < parent.n_children) {
-        const SNode c = nodes[parent.child_base + lane];
-        score = child_score(p, c, sq, cb, negate);
-        key = ((int)c.action << 8) | lane;
+      for (int j = lane; j < parent.n_children; j += 64) {       // one chunk of 64 children per round, usually one
+        const SNode c = nodes[parent.child_base + j];
+        const double sc = child_score(p, c, sq, cb, negate);
+        const int ky = ((int)c.action << 8) | j;                 // j < 256; children are in ascending action order
+        if (sc > score || (sc == score && ky > key)) { score = sc; key = ky; }
       }
       // max over (score, action): the larger action wins a tie (Explorer.py:100)
       for (int w = 32; w >= 1; w >>= 1) {
@@ -485,11 +509,12 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
   SNode* nodes = arena(p, g);
   const SNode root = nodes[p.root[g]];
   const int k = root.n_children, move = real.length;
-  if (k == 0 || p.sims_left[g] != 0 || p.pending[g] >= 0 || move >= MAX_MOVES) {
-    atomicOr(p.error_flag, move >= MAX_MOVES ? 32 : 4);
+  if (k == 0 || p.sims_left[g] != 0 || p.pending[g] >= 0 || move >= p.max_moves) {
+    atomicOr(p.error_flag, move >= p.max_moves ? 32 : 4);
     return;
   }
-  const size_t gm = (size_t)g * MAX_MOVES + move;
+  const size_t gm = (size_t)g * p.max_moves + move;
+  const int MAXC = p.maxc;
   int best = 0;
   for (int j = 0; j < k; ++j) {
     const SNode& c = nodes[root.child_base + j];
@@ -515,7 +540,7 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
   }
   int chosen_child = best;
   if (mode == 1) {                         // softmax_action (Explorer.py:187-199)
-    double e[MAXC];
+    double e[MAXC_LIMIT];
     int mx = 0;
     for (int j = 0; j < k; ++j) mx = max(mx, nodes[root.child_base + j].visit);
     for (int j = 0; j < k; ++j) e[j] = exp((double)(nodes[root.child_base + j].visit - mx));
@@ -533,7 +558,7 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
     // The root's children are exactly the legal actions, in ascending order.
     const double pv = 1.0 / (double)k;     // 1 / np.sum(mask): int8 sum -> exact integer
     double run = 0.0;
-    double cdf[MAXC];
+    double cdf[MAXC_LIMIT];
     for (int j = 0; j < k; ++j) { run = j == 0 ? pv : run + pv; cdf[j] = run; }
     chosen_child = k - 1;
     for (int j = 0; j < k; ++j) if (cdf[j] / cdf[k - 1] > u3) { chosen_child = j; break; }
@@ -634,7 +659,7 @@ nz_status check_flag(nz_scs_search* h, hipStream_t s) {
   S_HIP(h, hipMemcpyAsync(&f, h->p.error_flag, sizeof(f), hipMemcpyDeviceToHost, s));
   S_HIP(h, hipStreamSynchronize(s));
   if (f) return sfail(h, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 arena full, 2 visit table/path too short, "
-                                          "4 move ended before its search, 16 more than 64 legal actions, 32 game too long)", f);
+                                          "4 move ended before its search, 16 more legal actions than the bound computed at create, 32 game longer than that bound)", f);
   return NZ_OK;
 }
 }  // namespace
@@ -670,6 +695,34 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.training = cfg->training;
   p.softmax_moves = cfg->number_of_softmax_moves;
   p.negate_player = 2;                       // Explorer.py:124; SCS players are 0 and 1
+  {   // what the records must hold, from the game description (the reference has no limits at all):
+      //   decisions per game: one placement per unit, then per turn and unit at most ceil(movement / cheapest tile)
+      //     steps + 1 "end movement", 1 "end fighting" or 1 target choice, 1 selection as attacker, 1 confirmation
+      //   legal actions per position: the arrival tiles of a unit (placement), 7 per unit of the player to move
+      //     (6 directions + end movement; end fighting + <= 6 adjacent enemy tiles), 6 * stacking + 1 attackers
+    const ScsRules& R = h->host_rules;
+    int min_cost = 1 << 30, units[2] = {0, 0}, arrive = 0;
+    for (int t = 0; t < R.tiles; ++t) min_cost = std::min(min_cost, (int)R.cost[t]);
+    if (min_cost < 1) { delete h; return sfail(nullptr, NZ_ERR_ARG, "a terrain with movement cost < 1 makes a game's length unbounded"); }
+    long long moves = R.n_units;
+    for (int u = 0; u < R.n_units; ++u) {
+      units[R.u_player[u] ? 1 : 0] += 1;
+      moves += (long long)R.turns * ((R.u_mov[u] + min_cost - 1) / min_cost + 4);
+      int a = 0;
+      for (int t = 0; t < R.tiles; ++t) a += R.arrival[u][t] ? 1 : 0;
+      arrive = std::max(arrive, a);
+    }
+    const int children = std::max(std::max(arrive, 7 * std::max(units[0], units[1])), 6 * (int)R.stacking + 1);
+    if (children > MAXC_LIMIT) {
+      delete h;
+      return sfail(nullptr, NZ_ERR_ARG, "this game can have %d legal actions in one position; the search kernels hold %d "
+                                        "children per node", children, MAXC_LIMIT);
+    }
+    if (moves > 32000) { delete h; return sfail(nullptr, NZ_ERR_ARG, "a game of this description can last %lld decisions (limit 32000)", moves); }
+    p.maxc = (children + 63) / 64 * 64;
+    p.max_moves = (int32_t)moves + 8;
+  }
+  const int MAX_MOVES = p.max_moves, MAXC = p.maxc;
   p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
   p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
   {   // numpy's pairwise_sum over num_actions float32 entries (np.sum in Explorer.py:169) as a block program
@@ -827,6 +880,7 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int G = h->n_games;
+  const int MAX_MOVES = h->p.max_moves, MAXC = h->p.maxc;
   const ScsRules& R = h->host_rules;
   const int A = R.planes * R.tiles;
   int32_t nin = 0, npol = 0, nrows = 0, ncols = 0, nmax = 0;
@@ -931,6 +985,13 @@ nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host) {
   return NZ_OK;
 }
 
+nz_status nz_scs_search_limits(const nz_scs_search* h, int32_t* max_moves, int32_t* max_children) {
+  if (!h) return NZ_ERR_ARG;
+  if (max_moves) *max_moves = h->p.max_moves;
+  if (max_children) *max_children = h->p.maxc;
+  return NZ_OK;
+}
+
 nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves) {
   if (!h || !waves) return NZ_ERR_ARG;
   *waves = h->waves;
@@ -943,8 +1004,9 @@ nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree
   if (!h) return NZ_ERR_ARG;
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  const size_t GM = (size_t)h->n_games * MAX_MOVES;
   const SearchParams& p = h->p;
+  const size_t GM = (size_t)h->n_games * p.max_moves;
+  const int MAXC = p.maxc;
 #define CP(dst, src, n)                                                                          \
   if (dst) S_HIP(h, hipMemcpyAsync(dst, src, (n) * sizeof(*src), hipMemcpyDeviceToDevice, s))
   CP(actions, p.rec_action, GM); CP(tree_size, p.rec_tree_size, GM); CP(n_children, p.rec_children, GM);

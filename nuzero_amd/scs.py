@@ -142,8 +142,6 @@ class ScsSelfPlay:
     (device tensors in, device or host tensors out) -- e.g. a PyTorch model followed by softmax.
     Lock-step: one host round trip per simulation wave (C ABI nz_scs_search_*)."""
 
-    MAX_MOVES, MAX_CHILDREN = 256, 64
-
     def __init__(self, config, search_config, n_games, training=True, device=0, nodes_per_game=None):
         from .search_config import to_struct
         if not torch.cuda.is_available():
@@ -156,8 +154,8 @@ class ScsSelfPlay:
         sims = int(search_config["Simulation"]["mcts_simulations"])
         if nodes_per_game is None:
             # Two halves (32 B per node): at every re-root the kept subtree is copied to the other half, so a half
-            # holds the kept subtree plus one move's expansions (<= 64 children each).  A full half is reported
-            # (NZ_ERR_OVERFLOW), never silent.
+            # holds the kept subtree plus one move's expansions.  A full half is reported (NZ_ERR_OVERFLOW), never
+            # silent.
             nodes_per_game = 2 * (1 + sims * 160)
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
@@ -171,6 +169,10 @@ class ScsSelfPlay:
         if st != _lib.NZ_OK:
             raise _lib.NzError(st, (lib.nz_scs_search_last_error(None) or b"").decode())
         G = n_games
+        # decisions per game / children per node the records hold: bounded by the library from the game description
+        mm, mc = c_int32(0), c_int32(0)
+        self._check(lib.nz_scs_search_limits(self._h, byref(mm), byref(mc)))
+        self.MAX_MOVES, self.MAX_CHILDREN = int(mm.value), int(mc.value)
         self._images = torch.empty((G, c.channels, c.rows, c.cols), dtype=torch.float32, device=self.device)
         self._leaf_game = torch.empty((G,), dtype=torch.int32, device=self.device)
         self.evaluations = 0

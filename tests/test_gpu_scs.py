@@ -11,7 +11,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 @pytest.mark.parametrize("name,n_games", [("mirrored_5x5", 48), ("late_reinforcements_5x5", 48),
-                                          ("two_types_6x5", 48), ("ten_by_ten", 12)])
+                                          ("two_types_6x5", 48), ("ten_by_ten", 12), ("wide_arrival_10x10", 8),
+                                          ("reference_test_config", 12)])
 def test_scs_device_rules_equal_oracle(name, n_games):
     from nuzero_amd.scs import ScsBatch, ScsGameConfig
     from oracle.scs import ScsConfig, ScsGame
@@ -200,3 +201,53 @@ def test_gamer_and_network_manager_surface_for_scs(hexnet):
     assert tuple(logits.shape) == (5, ocfg.planes, ocfg.rows, ocfg.cols)
     scale = float(np.abs(p).max()) + 1.0
     assert np.max(np.abs(logits.cpu().numpy() - p)) / scale < 1e-5 and np.max(np.abs(value.cpu().numpy() - v)) < 1e-5
+
+
+@pytest.mark.parametrize("name,sims,n_games", [("wide_arrival_10x10", 24, 4), ("reference_test_config", 8, 3)])
+def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
+    """No fixed limits on the search: the reference's own test_config.yml (23 units, stacking 3: games of ~290 decisions,
+    past the 256 a record used to hold) and a map whose opening positions have 90 legal actions (more than the 64 lanes
+    of a wavefront: children are handled in chunks) play on the device exactly as on the oracle -- root noise, float32
+    pairwise sums and PUCT ties included."""
+    import torch
+    from scs_eval import evaluate_image
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from oracle import search as osearch
+    from oracle.scs import ScsConfig, ScsGame
+    path = os.path.join(GOLDEN, "scs_configs", name + ".yml")
+    cfg, ocfg = ScsGameConfig(path), ScsConfig(path)
+    A = cfg.num_actions
+
+    def device_ev(images):
+        out = [evaluate_image(im, A) for im in images.cpu().numpy()]
+        return (torch.from_numpy(np.stack([o[0] for o in out])), torch.from_numpy(np.array([o[1] for o in out], np.float32)))
+
+    search = {"Simulation": {"mcts_simulations": sims, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 2, "epsilon_softmax_exploration": 0.1,
+                              "epsilon_random_exploration": 0.05, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.3, "root_dist_beta": 1}}
+    seeds = list(range(70, 70 + n_games))
+    sp = ScsSelfPlay(cfg, search, n_games)
+    assert sp.MAX_CHILDREN % 64 == 0 and sp.MAX_CHILDREN >= (128 if name == "wide_arrival_10x10" else 64)
+    r = sp.play(device_ev, seeds)
+    sp.close()
+    most_children, longest = 0, 0
+    for g in range(n_games):
+        game, trace = ScsGame(ocfg), []
+        osearch.play_game(game, lambda gm: evaluate_image(gm.state_image()[0], A), search, np.random.RandomState(seeds[g]),
+                          trace=trace)
+        assert r["lengths"][g] == game.length and r["outcomes"][g] == game.terminal_value
+        longest = max(longest, game.length)
+        for m, mv in enumerate(trace):
+            k = len(mv["child_actions"])
+            most_children = max(most_children, k)
+            assert r["actions"][g, m] == mv["action"], (g, m)
+            assert r["child_action"][g, m, :k].tolist() == mv["child_actions"]
+            assert r["child_visit"][g, m, :k].tolist() == mv["child_visits"], (g, m)
+            assert r["child_prior"][g, m, :k].tolist() == mv["child_priors"], (g, m)
+            assert r["child_value_sum"][g, m, :k].tolist() == mv["child_value_sums"]
+    if name == "wide_arrival_10x10":
+        assert most_children > 64
+    else:
+        assert longest > 150 and sp.MAX_MOVES > 256
