@@ -309,13 +309,14 @@ nz_status nz_scs_status(nz_scs* h, int32_t* status_dev, void* stream);
  * takes (softmax probabilities, value) back (Explorer.py:159-181).  Any PyTorch model
  * can therefore drive the search (hex or square convs) until the fused kernel covers
  * SCS boards.  One move for all live games:
- *   root_children -> host draws gamma noise -> begin_move(noise [G][64])
+ *   root_children -> host draws gamma noise -> begin_move(noise [G][C], C = nz_scs_search_limits' max_children)
  *   repeat: select(images [G][C][R][Cc], leaf_game [G], &n) ; if n == 0 break ;
  *           evaluate images[0..n) ; expand(probs [n][A], value [n])
  *   end_move(uniforms [G][3])
  * nodes_per_game sizes each game's tree arena: two halves; at every re-root the new root's subtree is copied
  * into the other half (the rest of the tree is dropped), so a half must hold the kept subtree plus one move's
- * expansions (32 bytes per node; a full half is reported as NZ_ERR_OVERFLOW). */
+ * expansions (32 bytes per node; a full half is reported as NZ_ERR_OVERFLOW).  nodes_per_game <= 0: the default,
+ * 2 x (1 + simulations x 2.5 x the children bound). */
 typedef struct nz_scs_search nz_scs_search;
 nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* desc, const nz_search_cfg* cfg,
                                int32_t n_games, int32_t nodes_per_game, int32_t device);

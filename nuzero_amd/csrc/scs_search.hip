@@ -672,7 +672,8 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
                                int32_t nodes_per_game, int32_t device) {
   if (!out || !d || !cfg) return sfail(nullptr, NZ_ERR_ARG, "null argument");
   *out = nullptr;
-  if (n_games <= 0 || cfg->mcts_simulations <= 0 || nodes_per_game < 4) return sfail(nullptr, NZ_ERR_ARG, "bad sizes");
+  if (n_games <= 0 || cfg->mcts_simulations <= 0 || (nodes_per_game > 0 && nodes_per_game < 4))
+    return sfail(nullptr, NZ_ERR_ARG, "bad sizes");
   if (!cfg->keep_subtree) return sfail(nullptr, NZ_ERR_ARG, "keep_subtree = False is not supported (Gamer.py:78-79)");
   int n_dev = 0;
   if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
@@ -689,8 +690,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   memset(&p, 0, sizeof(p));
   const size_t G = n_games;
   p.n_games = n_games;
-  p.cap = nodes_per_game & ~1;                // two halves (compact_kernel)
-  p.half_cap = p.cap / 2;
+
   p.sims = cfg->mcts_simulations;
   p.training = cfg->training;
   p.softmax_moves = cfg->number_of_softmax_moves;
@@ -723,6 +723,13 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
     p.max_moves = (int32_t)moves + 8;
   }
   const int MAX_MOVES = p.max_moves, MAXC = p.maxc;
+  // Tree arena: two halves per game (compact_kernel copies the kept subtree into the other half at every re-root), so a
+  // half holds the kept subtree plus one move's expansions.  Default: 2.5 x the children bound per simulation (160 nodes
+  // for up to 64 children: what every configuration measured so far needed several times over); a full half is
+  // reported (NZ_ERR_OVERFLOW), never silent.
+  if (nodes_per_game <= 0) nodes_per_game = 2 * (1 + cfg->mcts_simulations * (5 * MAXC / 2));
+  p.cap = nodes_per_game & ~1;
+  p.half_cap = p.cap / 2;
   p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
   p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
   {   // numpy's pairwise_sum over num_actions float32 entries (np.sum in Explorer.py:169) as a block program

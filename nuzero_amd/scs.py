@@ -153,10 +153,7 @@ class ScsSelfPlay:
         self.n_games = n_games
         sims = int(search_config["Simulation"]["mcts_simulations"])
         if nodes_per_game is None:
-            # Two halves (32 B per node): at every re-root the kept subtree is copied to the other half, so a half
-            # holds the kept subtree plus one move's expansions.  A full half is reported (NZ_ERR_OVERFLOW), never
-            # silent.
-            nodes_per_game = 2 * (1 + sims * 160)
+            nodes_per_game = 0          # the library's default: scaled with the simulations and the children bound
         self._keep = (np.ascontiguousarray(c.terrain), np.ascontiguousarray(c.vp), np.ascontiguousarray(c.units),
                       np.ascontiguousarray(c.arrival))
         d = _lib.ScsDesc(rows=c.rows, cols=c.cols, turns=c.turns, stacking=c.stacking,
