@@ -395,6 +395,15 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
 /* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
  * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
 nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);
+/* The reference's optional inference cache (Explorer.py:146-155; Utils/Caches/KeylessCache.py:24-160, DictCache.py:4-85;
+ * handed to Gamer.play_game by AlphaZero.py:560-577) for nz_scs_search_play: one keyless hash table in HBM shared by the
+ * games of the engine -- a leaf whose state was evaluated before takes (probs, value) from the table instead of the
+ * network.  Results-neutral: a position's evaluation does not depend on the batch it was computed in.
+ *   max_entries > 0: (re)allocate an empty table of the largest power of two <= max_entries (KeylessCache.py:27-38);
+ *   0: no cache; < 0: empty the table (a new self-play round: the reference builds new Gamers, hence new caches).
+ * stats out4: hits, misses, entries in use, table size. */
+nz_status nz_scs_search_cache(nz_scs_search* h, int64_t max_entries);
+nz_status nz_scs_search_cache_stats(nz_scs_search* h, int64_t* out4_host);
 /* What the per-move records hold, bounded from the game description at create (the reference itself has no limits,
  * SCS_Game.py:395-484): decisions per game (= the M of nz_scs_search_export's [G, M] / [G, M, C] arrays) and children
  * per node (= C, a multiple of 64, at most 256; a description that allows more is rejected by nz_scs_search_create). */

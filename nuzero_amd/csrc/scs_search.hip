@@ -82,8 +82,20 @@ struct SearchParams {
   int32_t max_moves;       // decisions per game the records hold
   int32_t terminal_budget; // simulations ending in terminal leaves one game may run per wave
   int32_t image_row_stride; // > 0: leaf images are written as input rows of a board net (floats per row), else NCHW
+  // inference cache (keyless hash table shared by the games of the engine, see cache_put_kernel); c_bits == 0: off
+  int32_t c_bits;          // log2(entries)
+  int32_t c_wave;          // serial number of this simulation wave (arbitration of same-wave writers)
+  int32_t c_hit_base;      // evaluation slots [c_hit_base, c_hit_base + G) receive this wave's cache hits
+  uint64_t* c_id;          // [entries][2] the 128-bit hash of the state an entry holds (0, 0: empty)
+  float* c_probs;          // [entries][A] post-softmax probabilities
+  float* c_value;          // [entries]
+  int32_t* c_writer;       // [entries] last wave that wrote the entry
+  uint64_t* leaf_key;      // [G][2] hash of each queued (missed) leaf, by evaluation slot
+  int32_t* hit_count;      // [1] hits of this wave
+  float* eval_probs;       // [3 G][A] evaluations: the network's [0, G), cache hits [G, 2 G) / [2 G, 3 G) by wave parity
+  float* eval_value;       // [3 G]
   int32_t* error_flag;
-  int64_t* counters;       // [16] simulations, expansions; [2..7] shader ticks per phase of the NZ_SCS_STAMPS diagnostic build
+  int64_t* counters;       // [16] simulations, expansions; [8] cache hits, [9] misses, [10] entries in use; [2..7] shader ticks per phase of the NZ_SCS_STAMPS diagnostic build
   // records [G][max_moves]...
   int32_t* rec_action;
   int32_t* rec_tree_size;
@@ -198,7 +210,8 @@ __global__ void search_reset_kernel(SearchParams p) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g == 0) {
     *p.leaf_count = 0; *p.active_count = 0; *p.error_flag = 0;
-    for (int i = 0; i < 16; ++i) p.counters[i] = 0;
+    for (int i = 0; i < 16; ++i)
+      if (i < 8 || i > 10) p.counters[i] = 0;      // [8..10] belong to the inference cache (nz_scs_search_cache)
   }
   if (g >= p.n_games) return;
   Scs(*p.rules, p.real[g]).reset();
@@ -248,6 +261,57 @@ __global__ void begin_move_kernel(SearchParams p, const double* __restrict__ noi
   }
 }
 
+// ---- inference cache ------------------------------------------------------------------------------------------
+// The reference's optional cache (Explorer.py:146-155; Utils/Caches/KeylessCache.py:24-160: hash of the state tensor,
+// index bits select the slot, the remaining bits are stored as the entry's id; no keys kept) as one device table
+// shared by all games of the engine.  Key: a 128-bit hash of the game STATE the tensor is generated from (equal states
+// give equal tensors, so a hit returns what the network would compute; the reference's metrohash is a third-party
+// package that is not available here, and which hash is used only matters for which entries collide).  The table
+// is only READ inside wave_kernel and only WRITTEN by cache_put_kernel between two wave kernels, so no entry is
+// ever seen half-written.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {          // murmur3 finaliser
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+  return x;
+}
+// every lane returns the same (hi, lo): position-tagged words mixed per lane, combined across the wavefront
+__device__ __forceinline__ void state_hash_wave(const ScsState& st, int lane, uint64_t& hi, uint64_t& lo) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&st);
+  uint64_t a = 0, b = 0;
+  for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) {
+    const uint64_t v = ((uint64_t)(uint32_t)i << 32) | w[i];
+    a += mix64(v ^ 0x9e3779b97f4a7c15ull);
+    b += mix64(v * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+  }
+  for (int o = 32; o; o >>= 1) {
+    a += __shfl_xor((unsigned long long)a, o, 64);
+    b += __shfl_xor((unsigned long long)b, o, 64);
+  }
+  hi = mix64(a ^ (b >> 7));
+  lo = mix64(b ^ (a << 9));
+  if (hi == 0 && lo == 0) lo = 1;                                 // (0, 0) marks an empty entry
+}
+// After the network: the wave's evaluated leaves go into the table (KeylessCache.put: the newest entry replaces
+// what the slot held).  One wavefront per leaf; of two leaves of the same wave that map to the same entry the first
+// to arrive writes it, the other is dropped (both are valid values for their keys).
+__global__ __launch_bounds__(64) void cache_put_kernel(SearchParams p, const int32_t* __restrict__ n_leaves) {
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  if (slot >= *n_leaves) return;
+  const uint64_t hi = p.leaf_key[2 * slot], lo = p.leaf_key[2 * slot + 1];
+  const size_t e = (size_t)(lo & ((1ull << p.c_bits) - 1));
+  int old = 0;
+  if (lane == 0) old = atomicExch(&p.c_writer[e], p.c_wave);
+  old = __shfl(old, 0, 64);
+  if (old == p.c_wave) return;
+  if (lane == 0) {
+    if (p.c_id[2 * e] == 0 && p.c_id[2 * e + 1] == 0) atomicAdd((unsigned long long*)&p.counters[10], 1ull);
+    p.c_id[2 * e] = hi;
+    p.c_id[2 * e + 1] = lo;
+    p.c_value[e] = p.eval_value[slot];
+  }
+  const int A = p.num_actions;
+  for (int i = lane; i < A; i += 64) p.c_probs[e * A + i] = p.eval_probs[(size_t)slot * A + i];
+}
+
 // One simulation wave of one game, one wavefront per game (Explorer.run_mcts, :49-61):
 //   mode & 1  finish the pending expansion with the supplied evaluation (Explorer.py:162-181) and
 //             back its value up           probs [n_leaves][A] float32 post-softmax, value [n_leaves]
@@ -271,7 +335,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 #else
 #define NZ_STAMP(slot)
 #endif
-  if (g == 0 && lane == 0 && p.clear_counters != nullptr) { p.clear_counters[0] = 0; p.clear_counters[1] = 0; }
+  if (g == 0 && lane == 0 && p.clear_counters != nullptr) { p.clear_counters[0] = 0; p.clear_counters[1] = 0; p.clear_counters[2] = 0; }
   // everything this wave needs from the game's records in ONE round of loads (a chain of dependent loads, each
   // behind the branch on the previous one, costs a memory round trip per link)
   const uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
@@ -452,11 +516,30 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
       ++n_sim;
       continue;
     }
-    // leaf needs an evaluation: queue its state image and remember its legal actions
+    // leaf needs an evaluation: from the cache if its state is there (Explorer.py:147-149), else queue its state
+    // image for the network; either way remember its legal actions for the expansion at the start of the next wave
+    uint64_t key_hi = 0, key_lo = 0;
+    bool hit = false;
+    size_t entry = 0;
+    if (p.c_bits > 0) {
+      state_hash_wave(sc, lane, key_hi, key_lo);
+      entry = (size_t)(key_lo & ((1ull << p.c_bits) - 1));
+      hit = p.c_id[2 * entry] == key_hi && p.c_id[2 * entry + 1] == key_lo;      // uniform: every lane reads the same words
+    }
     int slot = 0;
     if (lane == 0) {
-      slot = atomicAdd(p.leaf_count, 1);
-      leaf_game[slot] = g;
+      if (hit) {
+        slot = p.c_hit_base + atomicAdd(p.hit_count, 1);
+        atomicAdd((unsigned long long*)&p.counters[8], 1ull);
+      } else {
+        slot = atomicAdd(p.leaf_count, 1);
+        leaf_game[slot] = g;
+        if (p.c_bits > 0) {
+          p.leaf_key[2 * slot] = key_hi;
+          p.leaf_key[2 * slot + 1] = key_lo;
+          atomicAdd((unsigned long long*)&p.counters[9], 1ull);
+        }
+      }
       p.pending[g] = slot;
       p.path_len[g] = plen;
       nodes[node].to_play = (int8_t)to_play;
@@ -467,6 +550,13 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 #endif
     uint32_t* m = p.leaf_mask + (size_t)g * MASK_WORDS;
     for (int i = lane; i < MASK_WORDS; i += 64) m[i] = smask[i];
+    if (hit) {                                  // the cached evaluation takes the place of the network's
+      for (int i = lane; i < A; i += 64) p.eval_probs[(size_t)slot * A + i] = p.c_probs[entry * A + i];
+      if (lane == 0) p.eval_value[slot] = p.c_value[entry];
+      queued = true;
+      NZ_STAMP(4);
+      break;
+    }
 #ifndef NZ_ABLATE_SCS_IMAGE   // timing experiment: no state image (results wrong)
     if (p.image_row_stride > 0)       // straight into the network's input rows: group of 16 slots, then cell, then slot
       scs_state_image_wave<true>(R, sc, images + ((size_t)(slot >> 4) * R.tiles * 16 + (slot & 15)) * p.image_row_stride,
@@ -627,7 +717,11 @@ struct nz_scs_search {
   int32_t *leaf_game = nullptr, *nchild = nullptr, *status = nullptr;
   double *noise = nullptr, *uniforms = nullptr;
   int64_t waves = 0;
-  int32_t* counters_base = nullptr;          // 4 ints: two (leaf, active) pairs
+  int32_t* counters_base = nullptr;          // 6 ints: two (leaf, active, cache hit) triples
+  // inference cache (nz_scs_search_cache)
+  int cache_bits = 0;
+  int64_t cache_entries = 0;
+  int32_t cache_wave = 0;
 };
 
 namespace {
@@ -770,7 +864,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   bool ok = dalloc(h, &rules, 1) && dalloc(h, &p.real, G) && dalloc(h, &p.scratch, G) &&
             dalloc(h, &p.nodes, G * (size_t)p.cap) && dalloc(h, &p.half, G) && dalloc(h, &p.node_count, G) && dalloc(h, &p.root, G) &&
             dalloc(h, &p.sims_left, G) && dalloc(h, &p.pending, G) && dalloc(h, &p.path, G * (size_t)p.max_path) &&
-            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 4) &&
+            dalloc(h, &p.path_len, G) && dalloc(h, &p.leaf_mask, G * MASK_WORDS) && dalloc(h, &p.leaf_count, 6) &&
             dalloc(h, &p.error_flag, 1) && dalloc(h, &p.counters, 16) && dalloc(h, &bias, (size_t)p.tab_len) &&
             dalloc(h, &sq, (size_t)p.tab_len) && dalloc(h, &p.rec_action, GM) && dalloc(h, &p.rec_tree_size, GM) &&
             dalloc(h, &p.rec_children, GM) && dalloc(h, &p.rec_bias, GM) && dalloc(h, &p.rec_root_value_sum, GM) &&
@@ -789,6 +883,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
     return sfail(nullptr, NZ_ERR_HIP, "upload failed");
   }
   p.active_count = p.leaf_count + 1;
+  p.hit_count = p.leaf_count + 2;
   p.clear_counters = nullptr;
   h->counters_base = p.leaf_count;
   p.rules = rules;
@@ -805,6 +900,7 @@ void nz_scs_search_destroy(nz_scs_search* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* q : h->allocs) (void)hipFree(q);
+  if (h->p.c_id) { (void)hipFree(h->p.c_id); (void)hipFree(h->p.c_probs); (void)hipFree(h->p.c_value); (void)hipFree(h->p.c_writer); }
   delete h;
 }
 
@@ -838,7 +934,8 @@ nz_status nz_scs_search_select(nz_scs_search* h, float* images_dev, int32_t* lea
   if (!h || !images_dev || !leaf_game_dev || !n_leaves_host) return NZ_ERR_ARG;
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 2 * sizeof(int32_t), s));
+  S_HIP(h, hipMemsetAsync(h->p.leaf_count, 0, 3 * sizeof(int32_t), s));
+  h->p.c_bits = 0;                            // the cache lives in the library's own move loop (nz_scs_search_play)
   h->p.terminal_budget = 1 << 30;             // run on until a leaf needs an evaluation, as this API promises
   h->p.image_row_stride = 0;                  // NCHW images for the caller
   h->p.clear_counters = nullptr;
@@ -901,8 +998,10 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
   int32_t row_stride = 0;
   if (nz_boardnet_input_rows(net, &net_rows, &row_stride) != NZ_OK) return sfail(h, NZ_ERR_ARG, "bad network handle");
   if (!h->images) {
-    const bool ok = dalloc(h, &h->images, (size_t)G * R.channels * R.tiles) && dalloc(h, &h->probs, (size_t)G * A) &&
-                    dalloc(h, &h->value, (size_t)G) && dalloc(h, &h->leaf_game, (size_t)G) &&
+    // evaluations: the network's in slots [0, G), cache hits in [G, 2 G) / [2 G, 3 G) by wave parity
+    const bool ok = dalloc(h, &h->images, (size_t)G * R.channels * R.tiles) && dalloc(h, &h->probs, (size_t)3 * G * A) &&
+                    dalloc(h, &h->value, (size_t)3 * G) && dalloc(h, &h->leaf_game, (size_t)G) &&
+                    dalloc(h, &h->p.leaf_key, (size_t)2 * G) &&
                     dalloc(h, &h->nchild, (size_t)G) && dalloc(h, &h->status, (size_t)G * 7) &&
                     dalloc(h, &h->noise, (size_t)G * MAXC) && dalloc(h, &h->uniforms, (size_t)G * 3);
     if (!ok) return sfail(h, NZ_ERR_HIP, "device allocation failed");
@@ -952,15 +1051,21 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
     }
     hipLaunchKernelGGL(begin_move_kernel, dim3(G), dim3(64), 0, s, h->p, h->noise);
     h->p.image_row_stride = row_stride;
-    S_HIP(h, hipMemsetAsync(counters, 0, 4 * sizeof(int32_t), s));
+    S_HIP(h, hipMemsetAsync(counters, 0, 6 * sizeof(int32_t), s));
+    h->p.eval_probs = h->probs;
+    h->p.eval_value = h->value;
+    h->p.c_bits = h->cache_bits;
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     const int sims = h->cfg.mcts_simulations;
     for (int w = 0;; ++w) {
       // two (leaf, active) counter pairs: wave w counts into pair w & 1 and zeroes the other one for wave w + 1
-      h->p.leaf_count = counters + 2 * (w & 1);
+      h->p.leaf_count = counters + 3 * (w & 1);
       h->p.active_count = h->p.leaf_count + 1;
-      h->p.clear_counters = counters + 2 * ((w + 1) & 1);
+      h->p.hit_count = h->p.leaf_count + 2;
+      h->p.clear_counters = counters + 3 * ((w + 1) & 1);
+      h->p.c_wave = ++h->cache_wave;
+      h->p.c_hit_base = G * (1 + (w & 1));
       hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, net_rows, h->leaf_game);
       ++h->waves;
       if ((w & 7) == 7 || w >= sims - 1) {
@@ -972,13 +1077,60 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
       }
       if (nz_boardnet_forward_rows(net, G, h->p.leaf_count, nullptr, h->probs, h->value, stream) != NZ_OK)
         return sfail(h, NZ_ERR_HIP, "network: %s", nz_boardnet_last_error(net));
+      if (h->cache_bits > 0)                   // the leaves the network just evaluated enter the table (KeylessCache.put)
+        hipLaunchKernelGGL(cache_put_kernel, dim3(G), dim3(64), 0, s, h->p, h->p.leaf_count);
     }
     st = nz_scs_search_end_move(h, h->uniforms, stream);
     if (st != NZ_OK) return st;
   }
   h->p.leaf_count = counters;
   h->p.active_count = counters + 1;
+  h->p.hit_count = counters + 2;
   h->p.clear_counters = nullptr;
+  return NZ_OK;
+}
+
+// The reference's inference cache for the library's move loop (cache_choice "keyless" / "dict" of Gamer,
+// Training/Gamer.py:20,53-55; KeylessCache.py:27-38: the table size is the largest power of two <= max_size).
+// max_entries > 0: (re)allocate an empty table; 0: switch the cache off; < 0: empty the table, keep it.
+nz_status nz_scs_search_cache(nz_scs_search* h, int64_t max_entries) {
+  if (!h) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  SearchParams& p = h->p;
+  const size_t A = (size_t)p.num_actions;
+  if (max_entries >= 0) {
+    if (p.c_id) { (void)hipFree(p.c_id); (void)hipFree(p.c_probs); (void)hipFree(p.c_value); (void)hipFree(p.c_writer); }
+    p.c_id = nullptr; p.c_probs = nullptr; p.c_value = nullptr; p.c_writer = nullptr;
+    h->cache_bits = 0; h->cache_entries = 0;
+    if (max_entries == 0) return NZ_OK;
+    int bits = 0;
+    while ((2ll << bits) <= max_entries && bits < 30) ++bits;          // closest power of two under max_entries
+    if (bits == 0) bits = 1;
+    const size_t n = (size_t)1 << bits;
+    if (hipMalloc((void**)&p.c_id, n * 2 * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&p.c_probs, n * A * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p.c_value, n * sizeof(float)) != hipSuccess || hipMalloc((void**)&p.c_writer, n * sizeof(int32_t)) != hipSuccess)
+      return sfail(h, NZ_ERR_HIP, "cache allocation failed (%zu entries of %zu actions)", n, A);
+    h->cache_bits = bits;
+    h->cache_entries = (int64_t)n;
+  }
+  if (h->cache_bits > 0) {
+    const size_t n = (size_t)h->cache_entries;
+    S_HIP(h, hipMemset(p.c_id, 0, n * 2 * sizeof(uint64_t)));
+    S_HIP(h, hipMemset(p.c_writer, 0, n * sizeof(int32_t)));
+    S_HIP(h, hipMemset(p.counters + 8, 0, 3 * sizeof(int64_t)));
+    h->cache_wave = 0;
+  }
+  return NZ_OK;
+}
+
+// out4: hits, misses, entries in use, table size (Cache.get_hit_ratio / length / get_fill_ratio)
+nz_status nz_scs_search_cache_stats(nz_scs_search* h, int64_t* out4_host) {
+  if (!h || !out4_host) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  S_HIP(h, hipMemcpy(out4_host, h->p.counters + 8, 3 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  out4_host[3] = h->cache_entries;
   return NZ_OK;
 }
 

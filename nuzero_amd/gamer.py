@@ -46,6 +46,31 @@ class GameRecord:
         return self.terminal_value
 
 
+class DeviceCacheStats:
+    """What AlphaZero.run_selfplay reads of the cache a Gamer hands back (AlphaZero.py:553-568), for the device table of
+    nz_scs_search_cache: hit ratio, entries, fill ratio.  The table itself stays on the device and is shared by all games
+    of the round already, so `update` (merging another game's cache, KeylessCache.py:89-104) has nothing left to do."""
+
+    def __init__(self, stats, update_threshold=0.8):
+        self.stats, self.update_threshold = stats, update_threshold
+
+    def get_hit_ratio(self):
+        n = self.stats["hits"] + self.stats["misses"]
+        return self.stats["hits"] / n if n else 0.0
+
+    def length(self):
+        return self.stats["entries"]
+
+    def get_fill_ratio(self):
+        return self.stats["entries"] / self.stats["size"] if self.stats["size"] else 0.0
+
+    def get_update_threshold(self):
+        return self.update_threshold
+
+    def update(self, other):
+        return None
+
+
 class DisabledCache:
     """Cache-shaped object for callers that expect one back from play_game
     (AlphaZero.py:553-568).  hit_ratio 0: the engine evaluates every leaf; 1: every leaf is
@@ -137,14 +162,16 @@ class Gamer:
         self._wrapped = None
         if self.is_scs:
             # game_args = [config path] as for SCS_Game(cfg) (Games/SCS/SCS_Game.py:45); every game of the round runs
-            # concurrently; the inference cache of the reference has no device counterpart here
+            # concurrently
             from .scs import ScsGameConfig, ScsSelfPlay
             if not game_args:
                 raise ValueError("SCS needs game_args = [path of the game config]")
-            if self.cache_choice != "disabled":
-                raise NotImplementedError("SCS: cache_choice must be 'disabled'")
             self.scs_config = ScsGameConfig(game_args[0])
             self.engine = ScsSelfPlay(self.scs_config, search_config, num_games, training=True, device=device)
+            if self.cache_choice != "disabled":
+                # "keyless" and "dict" (general_utils.py:14-24) both become the device table: a 128-bit hash is stored
+                # instead of the key (KeylessCache), sized like KeylessCache(size_estimate)
+                self.engine.cache(size_estimate)
             self._board_net = None
             return
         self.engine = SelfPlayEngine(search_config, num_games, training=True, device=device,
@@ -207,6 +234,8 @@ class Gamer:
             c = self.scs_config
             self._board_net = nm.board_net(c.rows, c.cols, self.num_games, self.recurrent_iterations, self.device)
             self._loaded = (id(nm), nm.version)
+        if self.cache_choice != "disabled":
+            self.engine.cache_clear()                  # a new round: new caches (AlphaZero.py:525-537)
         r = self.engine.play_native(self._board_net, range(self.base_seed, self.base_seed + self.num_games))
         self.base_seed += self.num_games
         stats = round_stats(r)
@@ -225,6 +254,8 @@ class Gamer:
         """Reference signature (Gamer.py:39-97): (stats, cache).  With num_games > 1
         the stats are those of the round's first game; use play_games for all."""
         _, stats = self.play_games()
+        if self.is_scs and self.cache_choice != "disabled":
+            return stats[0], DeviceCacheStats(self.engine.cache_stats(), 0.8 if self.cache_choice == "keyless" else 0.7)
         return stats[0], DisabledCache(0.0 if self.cache_choice == "disabled" else 1.0)
 
     def play_forever(self):

@@ -265,6 +265,21 @@ class ScsSelfPlay:
         out["waves"] = int(waves.value)
         return out
 
+    def cache(self, max_entries):
+        """The reference's inference cache for play_native (KeylessCache(max_size), Utils/Caches/KeylessCache.py:24-160):
+        a device hash table of the largest power of two <= max_entries, shared by the engine's games; 0 switches it
+        off.  Results do not change (tests/test_gpu_scs.py)."""
+        self._check(lib.nz_scs_search_cache(self._h, int(max_entries)))
+
+    def cache_clear(self):
+        """Empty the table (the reference builds new caches for every self-play round, AlphaZero.py:525-577)."""
+        self._check(lib.nz_scs_search_cache(self._h, -1))
+
+    def cache_stats(self):
+        out = (ctypes.c_int64 * 4)()
+        self._check(lib.nz_scs_search_cache_stats(self._h, out))
+        return {"hits": int(out[0]), "misses": int(out[1]), "entries": int(out[2]), "size": int(out[3])}
+
     def phase_ticks(self):
         """Diagnostic build only (-DNZ_SCS_STAMPS): shader ticks per phase of the wave kernel, summed over games."""
         out = (ctypes.c_int64 * 6)()

@@ -226,7 +226,7 @@ def test_fused_loss_equals_the_reference(name):
             logits.grad = values.grad = None
             v_loss, p_loss, c_loss = calculate_loss((logits, values), tp, tv, pname, vname, norm)
             c_loss.backward()
-            got = np.array([float(v_loss), float(p_loss), float(c_loss)])
+            got = np.array([v_loss.item(), p_loss.item(), c_loss.item()])
             want = kat[key + "_losses"]
             assert np.all(np.abs(got - want) <= 2e-6 * np.abs(want) + 1e-7), (key, got, want)       # 2e-6 relative
             for g, w in ((logits.grad, kat[key + "_dlogits"]), (values.grad, kat[key + "_dvalues"])):

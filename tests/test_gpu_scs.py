@@ -251,3 +251,61 @@ def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
         assert most_children > 64
     else:
         assert longest > 150 and sp.MAX_MOVES > 256
+
+
+@pytest.mark.parametrize("entries", [1 << 16, 64])
+def test_scs_inference_cache_is_results_neutral(entries):
+    """The device inference cache (KeylessCache semantics: index bits + stored hash, newest entry replaces) for the
+    library's move loop: the games of a round are the same with and without it, also with a table so small that entries
+    are replaced all the time; hits happen (games share positions) and the statistics add up."""
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    path = os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsGameConfig(path)
+    G = 48
+    w = synthetic_weights(6, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 2), 2.0)
+    net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=2, max_batch=G)
+    net.set_weights(w)
+    search = {"Simulation": {"mcts_simulations": 30, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.15, "root_dist_beta": 1}}
+    seeds = list(range(300, 300 + G))
+    plain = ScsSelfPlay(cfg, search, G)
+    ra = plain.play_native(net, seeds)
+    cached = ScsSelfPlay(cfg, search, G)
+    cached.cache(entries)
+    rb = cached.play_native(net, seeds)
+    for k in ("lengths", "outcomes", "actions", "tree_size", "n_children"):
+        assert np.array_equal(ra[k], rb[k]), k
+    for g in range(G):
+        n = ra["lengths"][g]
+        assert np.array_equal(ra["root_value_sum"][g, :n], rb["root_value_sum"][g, :n])
+        for m in range(n):
+            c = ra["n_children"][g, m]
+            for k in ("child_action", "child_visit", "child_prior", "child_value_sum"):
+                assert np.array_equal(ra[k][g, m, :c], rb[k][g, m, :c]), (k, g, m)
+    st = cached.cache_stats()
+    assert st["size"] == entries and st["hits"] > 0 and st["hits"] + st["misses"] == rb["expansions"] == ra["expansions"]
+    assert 0 < st["entries"] <= min(st["size"], st["misses"])
+    # a second round on an emptied table: same again; a kept table: more hits, same games
+    cached.cache_clear()
+    assert cached.cache_stats()["entries"] == 0
+    rc = cached.play_native(net, seeds)
+    assert np.array_equal(rc["actions"], ra["actions"]) and cached.cache_stats()["hits"] == st["hits"]
+    rd = cached.play_native(net, seeds)
+    assert np.array_equal(rd["actions"], ra["actions"])
+    if entries >= 1 << 16:
+        assert cached.cache_stats()["hits"] > 2 * st["hits"]
+    plain.close(); cached.close(); net.close()
+    # the reference's surface: Gamer(..., cache_choice="keyless", cache_max) hands back a cache with these statistics
+    class SCS_Game:
+        pass
+    gamer = Gamer(None, Network_Manager(w), SCS_Game, [path], 0, search, 1, "keyless", 1 << 12, num_games=8, records=False)
+    stats, cache = gamer.play_game()
+    assert 0.0 < cache.get_hit_ratio() < 1.0 and 0 < cache.length() <= 1 << 12 and 0.0 < cache.get_fill_ratio() <= 1.0
+    assert cache.get_update_threshold() == 0.8 and cache.update(cache) is None
