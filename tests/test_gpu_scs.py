@@ -296,7 +296,9 @@ def test_scs_inference_cache_is_results_neutral(entries):
     cached.cache_clear()
     assert cached.cache_stats()["entries"] == 0
     rc = cached.play_native(net, seeds)
-    assert np.array_equal(rc["actions"], ra["actions"]) and cached.cache_stats()["hits"] == st["hits"]
+    # (which of two leaves of one wave takes a shared entry depends on timing, so the hit count may differ a little
+    # between two runs; the games may not)
+    assert np.array_equal(rc["actions"], ra["actions"]) and abs(cached.cache_stats()["hits"] - st["hits"]) <= 0.2 * st["hits"]
     rd = cached.play_native(net, seeds)
     assert np.array_equal(rd["actions"], ra["actions"])
     if entries >= 1 << 16:
