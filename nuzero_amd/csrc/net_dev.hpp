@@ -423,8 +423,28 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   };
   if constexpr (STAMPS) ts = __builtin_amdgcn_s_memtime();
 
+  // The next job's descriptor is fetched while this job computes -- with VECTOR loads (every lane reads the same six
+  // words, v_readfirstlane makes them scalars again).  As a scalar load it would share lgkmcnt with the K loop's LDS
+  // operand reads and return out of order with them; that variant computes wrong outputs.
+  static_assert(sizeof(NetJob) == 24, "six dwords");
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                  // a zero the compiler must keep in a vector register
+  const uint32_t* jw = reinterpret_cast<const uint32_t*>(jobs) + vzero;
+  uint32_t nw[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) nw[i] = jw[i];
   for (int j = 0; j < n_jobs; ++j) {
-    const NetJob job = jobs[j];
+    NetJob job;
+    {
+      uint32_t cw[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) cw[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw[i]);
+      __builtin_memcpy(&job, cw, sizeof(job));
+    }
+    if (j + 1 < n_jobs) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) nw[i] = jw[(j + 1) * 6 + i];
+    }
     if (job.og != OG_NONE) {
       const float* w_after = (job.kgroups > 0 && job.next_w_off >= 0) ? W + job.next_w_off : nullptr;
       switch (job.og) {
