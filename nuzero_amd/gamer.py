@@ -167,7 +167,11 @@ class Gamer:
             if not game_args:
                 raise ValueError("SCS needs game_args = [path of the game config]")
             self.scs_config = ScsGameConfig(game_args[0])
-            self.engine = ScsSelfPlay(self.scs_config, search_config, num_games, training=True, device=device)
+            # `concurrent_games` trees play the round's `num_games` games in ceil(num_games / concurrent_games) batches
+            # (the reference's ActorPool of num_actors Gamers over num_games_per_step games, AlphaZero.py:525-577; games
+            # are independent and seeded by their index, so the batching does not change any game)
+            self.concurrent = min(int(concurrent_games or num_games), num_games)
+            self.engine = ScsSelfPlay(self.scs_config, search_config, self.concurrent, training=True, device=device)
             if self.cache_choice != "disabled":
                 # "keyless" and "dict" (general_utils.py:14-24) both become the device table: a 128-bit hash is stored
                 # instead of the key (KeylessCache), sized like KeylessCache(size_estimate)
@@ -232,22 +236,27 @@ class Gamer:
             if self._board_net is not None:
                 self._board_net.close()
             c = self.scs_config
-            self._board_net = nm.board_net(c.rows, c.cols, self.num_games, self.recurrent_iterations, self.device)
+            self._board_net = nm.board_net(c.rows, c.cols, self.concurrent, self.recurrent_iterations, self.device)
             self._loaded = (id(nm), nm.version)
         if self.cache_choice != "disabled":
             self.engine.cache_clear()                  # a new round: new caches (AlphaZero.py:525-537)
-        r = self.engine.play_native(self._board_net, range(self.base_seed, self.base_seed + self.num_games))
-        self.base_seed += self.num_games
-        stats = round_stats(r)
         on_device = hasattr(self.buffer, "save_scs_games")
-        if on_device:
-            self.buffer.save_scs_games(self.engine, self.engine.export_device(), self.game_index)
-        if not self.records:
-            return [], stats
-        records = scs_game_records(self.engine, r)
-        if self.buffer is not None and not on_device:
-            for rec in records:
-                self.buffer.save_game(rec, self.game_index)
+        records, stats = [], []
+        C = self.concurrent
+        for start in range(0, self.num_games, C):
+            n = min(C, self.num_games - start)
+            seeds = [self.base_seed + start + i for i in range(n)] + [0] * (C - n)     # a short last batch is padded
+            r = self.engine.play_native(self._board_net, seeds)
+            stats += round_stats({k: r[k][:n] for k in ("lengths", "tree_size", "n_children", "bias")})
+            if on_device:
+                self.buffer.save_scs_games(self.engine, self.engine.export_device(), self.game_index, n_games=n)
+            if self.records:
+                batch = scs_game_records(self.engine, r)[:n]
+                records += batch
+                if self.buffer is not None and not on_device:
+                    for rec in batch:
+                        self.buffer.save_game(rec, self.game_index)
+        self.base_seed += self.num_games
         return records, stats
 
     def play_game(self, cache=None):

@@ -220,15 +220,18 @@ class DeviceReplayBuffer:
                      visits=ex["visits"].contiguous())
         return lengths
 
-    def save_scs_games(self, selfplay, result_device, game_index):
-        """Every game of a finished SCS round (nuzero_amd.scs.ScsSelfPlay): the per-move state images are regenerated
-        on the device by replaying the recorded actions through the device rules, one append per move; the policy
-        targets come from the root's (action, visit) lists (SCS_Game.py:1517-1521)."""
+    def save_scs_games(self, selfplay, result_device, game_index, n_games=None):
+        """The (first `n_games`) games of a finished SCS round (nuzero_amd.scs.ScsSelfPlay): the per-move state images
+        are regenerated on the device by replaying the recorded actions through the device rules, one append per move;
+        the policy targets come from the root's (action, visit) lists (SCS_Game.py:1517-1521)."""
         from .scs import ScsBatch
         cfg, G = selfplay.cfg, selfplay.n_games
         r = result_device
         lengths = r["lengths"].cpu().numpy()
-        dst = self.index.save_games(lengths, game_index)
+        n_keep = G if n_games is None else int(n_games)
+        dst = np.full((G, int(lengths.max())), -1, np.int64)
+        kept = self.index.save_games(lengths[:n_keep], game_index)
+        dst[:n_keep, :kept.shape[1]] = kept
         batch = ScsBatch(cfg, G, device=self.device.index or 0)
         outcomes = r["outcomes"].to(torch.int32).contiguous()
         moves = torch.arange(int(lengths.max()), device=self.device)
@@ -240,7 +243,7 @@ class DeviceReplayBuffer:
                                    r["n_children"][:, m].contiguous()))
             batch.step(actions[:, m].contiguous())
         batch.close()
-        return lengths
+        return lengths[:n_keep]
 
     def save_game(self, game, game_index):
         """ReplayBuffer.save_game (ReplayBuffer.py:24-36) for one game object with the reference's attributes

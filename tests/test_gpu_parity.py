@@ -600,3 +600,32 @@ def test_end_to_end_agreement_with_the_real_network():
     if out_dir:
         with open(os.path.join(out_dir, "e2e_agreement.json"), "w") as f:
             json.dump(report, f, indent=1)
+
+
+def test_baseline_config_3_share_of_one_gpu_equals_c_oracle():
+    """BASELINE configs[2] (400 simulations/move, 8192 games over 8 GPUs) as ONE rank plays it: its shard of 1024 games
+    (seeds of rank 5: nuzero_amd.dist.shard_seeds), 400 simulations/move, network fused into the search; the C oracle
+    replays every game from the GPU network's own outputs -- all arrays identical.  (The 8-GPU split itself is the gather
+    of tests/test_host_logic.py::test_round_on_two_ranks_gloo; there is no multi-GPU hardware in this pool.)"""
+    from nuzero_amd import dist as nzdist
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import cref
+    cfg = legacy_ttt_search_config(400)
+    n_games, rank = 1024, 5
+    base = nzdist.shard_seeds(90000, n_games, rank)
+    assert base == 90000 + 5 * 1024
+    eng = _engine(cfg, n_games)
+    eng.set_weights(synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True))
+    table = _gpu_table(eng)
+    eng.play(base_seed=base)
+    r = eng.export(trace=True)
+    c = eng.counters()
+    assert eng.live_games() == 0
+    o = cref.play_games(table, cfg, [base + g for g in range(n_games)])
+    for k in ("lengths", "outcomes", "actions", "visits", "tree_size", "n_children", "bias", "child_prior",
+              "child_value_sum", "root_value_sum"):
+        assert np.array_equal(r[k], o[k]), k
+    assert c["simulations"] == o["simulations"] == int(r["lengths"].sum()) * 400 and c["expansions"] == o["expansions"]
+    assert (r["tree_size"][:, 0] == 400).all()
+    eng.close()

@@ -311,3 +311,35 @@ def test_scs_inference_cache_is_results_neutral(entries):
     stats, cache = gamer.play_game()
     assert 0.0 < cache.get_hit_ratio() < 1.0 and 0 < cache.length() <= 1 << 12 and 0.0 < cache.get_fill_ratio() <= 1.0
     assert cache.get_update_threshold() == 0.8 and cache.update(cache) is None
+
+
+def test_scs_round_larger_than_the_concurrent_trees():
+    """Gamer(num_games=10, concurrent_games=4) on SCS: the round is played in batches of 4 trees (the reference's
+    ActorPool: num_actors workers over num_games_per_step games); every game equals the one a 10-tree engine plays."""
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    from oracle.scs import ScsConfig
+    path = os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    ocfg = ScsConfig(path)
+    nm = Network_Manager(synthetic_weights(8, convnet_param_shapes(ocfg.channels, ocfg.planes, 3, 32, 2), 2.0))
+
+    class SCS_Game:
+        pass
+
+    search = {"Simulation": {"mcts_simulations": 10, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.2, "root_dist_beta": 1}}
+    out = {}
+    for conc in (10, 4):
+        rb = ReplayBuffer(100, 8)
+        g = Gamer(rb, nm, SCS_Game, [path], 1, search, 1, "disabled", num_games=10, concurrent_games=conc, base_seed=40)
+        records, stats = g.play_games()
+        assert len(records) == len(stats) == 10 and rb.len() == sum(r.length for r in records)
+        out[conc] = (records, stats)
+    for ra, rb_ in zip(out[10][0], out[4][0]):
+        assert ra.length == rb_.length and ra.terminal_value == rb_.terminal_value and ra.child_policy == rb_.child_policy
+    assert out[10][1] == out[4][1]
