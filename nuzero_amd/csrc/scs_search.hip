@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64) void cache_put_kernel(SearchParams p, const int
 __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, const float* __restrict__ probs,
                                                    const float* __restrict__ value, float* __restrict__ images,
                                                    int32_t* __restrict__ leaf_game) {
-  __shared__ ScsRules R;
+  __shared__ __attribute__((aligned(16))) ScsRules R;
   __shared__ ScsState sc;
   __shared__ uint32_t smask[MASK_WORDS];
   __shared__ int sidx[MAXC_LIMIT];
@@ -443,11 +443,21 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   int sims_left = expanding ? sims_in - 1 : sims_in;
   if (sims_left <= 0) return;
 
-  {
+  {   // rules -> LDS: 16 bytes per lane and load, all loads in flight before the first store
     static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&R);
-    for (int i = lane; i < (int)(sizeof(ScsRules) / 4); i += 64) dst[i] = src[i];
+    constexpr int N16 = (int)(sizeof(ScsRules) / 16), PER_LANE = (N16 + 63) / 64;
+    const uint4* src = reinterpret_cast<const uint4*>(p.rules);
+    uint4* dst = reinterpret_cast<uint4*>(&R);
+    uint4 tmp[PER_LANE];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j)
+      if (j * 64 + lane < N16) tmp[j] = src[j * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; ++j)
+      if (j * 64 + lane < N16) dst[j * 64 + lane] = tmp[j];
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(p.rules);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(&R);
+    for (int i = N16 * 4 + lane; i < (int)(sizeof(ScsRules) / 4); i += 64) d4[i] = s4[i];
   }
   NZ_STAMP(1);                                  // rules -> LDS
   long n_sim = 0;

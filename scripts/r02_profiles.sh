@@ -12,3 +12,9 @@ python3 $R/scripts/pmc_traffic.py $(ls /tmp/p_f/*/*counter_collection.csv | head
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_s1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_s1.log 2>&1 || exit 1
 python3 $R/scripts/pmc_summary.py $(ls /tmp/p_s1/*/*counter_collection.csv | head -1) "selfplay_kernel<false>" > $O/pmc_selfplay_kernel_sq.txt
 cat $O/pmc_selfplay_kernel_sq.txt
+# SCS configs[3]: kernel stats of one round (bench_scs.py --games 1024) and the one-launch network alone
+timeout -k 10 300 python3 $R/bench_scs.py --games 1024 > $O/scs_1024.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_scs -- python3 $R/bench_scs.py --games 1024 > $O/scs_rocprof.log 2>&1 || exit 1
+cp $(ls /tmp/p_scs/*/*kernel_stats.csv | head -1) $O/scs_1024_kernel_stats.csv
+timeout -k 10 200 python3 $R/scripts/fused_only.py 50 > $O/fused_net_forward.txt 2>&1 || exit 1
+tail -1 $O/scs_1024.log; cat $O/fused_net_forward.txt
