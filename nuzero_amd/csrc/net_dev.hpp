@@ -361,6 +361,9 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
     }
   } else {                                     // value: mean over (C=1,H,W), tanh (blocks.py:82-84)
     if constexpr (OMASK == 0x1FF) {
+      int l2 = lane;                           // as for the policy: no address hoisted out of the job loop
+      asm volatile("" : "+v"(l2));
+      const int pos = l2 & 15, quad = l2 >> 4;
       if (job.nt == 0 && quad == 0 && pos < n_valid) {
         float s = 0.0f;
 #pragma unroll

@@ -132,9 +132,12 @@ __device__ __forceinline__ int expand_row(const TreeParams& p, Arena t, int leaf
   }
   if (legal) {
     const int c = base + __popc(empty & ((1u << sub) - 1u));
-    TNode n = fresh_node((uint32_t)sub);
-    n.prior = pd / total;
-    t[c] = n;
+    t[c].value_sum = 0.0;                     // (the three padding words are never read: not written either)
+    t[c].q = 0.0;
+    t[c].prior = pd / total;
+    t[c].visit = 0;
+    t[c].first = 0u;
+    t[c].meta = pack_meta(0u, (uint32_t)sub, TO_PLAY_UNSET, 0u);
   }
   if (sub == 0) {
     t[leaf].first = (uint32_t)base;
