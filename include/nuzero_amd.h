@@ -332,10 +332,10 @@ nz_status nz_scs_search_expand(nz_scs_search* h, const float* probs_dev, const f
 nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, void* stream);
 /* status_dev int32[G][7] as nz_scs_status */
 nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream);
-/* Per move m < 256 of game g (dev pointers, any may be NULL): actions int32[G][256] (-1 past the
- * end), tree_size, n_children int32[G][256], bias, root_value_sum double[G][256]; the root's
- * children in child order: child_action, child_visit int32[G][256][64], child_prior,
- * child_value_sum double[G][256][64].  counters_host int64[2]: simulations, expansions. */
+/* Per move m < M of game g (dev pointers, any may be NULL; M = max_moves, C = max_children of
+ * nz_scs_search_limits): actions int32[G][M] (-1 past the end), tree_size, n_children int32[G][M], bias,
+ * root_value_sum double[G][M]; the root's children in child order: child_action, child_visit int32[G][M][C],
+ * child_prior, child_value_sum double[G][M][C].  counters_host int64[2]: simulations, expansions. */
 nz_status nz_scs_search_export(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
                                double* bias, double* root_value_sum, int32_t* child_action,
                                int32_t* child_visit, double* child_prior, double* child_value_sum,
