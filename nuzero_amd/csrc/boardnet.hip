@@ -476,17 +476,21 @@ constexpr int FUSED_BUFFERS = 8;
 constexpr int FUSED_WAVES = 16;             // wavefronts per workgroup: a layer's jobs run side by side, four per SIMD
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
 constexpr int FUSED_PAD = 4;               // floats added to every LDS row: spreads the 16 rows of a tile over the banks
-struct FusedOp {
-  int32_t src0, src1, res, dst;            // LDS buffer ids (-1: none)
-  int32_t kg0, kg1, ntiles, act;           // 16-channel groups of each source, 16-channel output tiles
+struct FusedOp {                           // one conv layer, every LDS address resolved by the host (float offsets)
   const float* w;                          // packed weights (PackedConv::dev)
-  int32_t w_lds, pad;                      // 1: the layer's weights are staged in LDS (they fit the weight buffer)
+  int32_t off0, cs0, off1, cs1;            // sources: offset and floats per row (off1 = -1: one source)
+  int32_t offd, csd, offr, csr;            // destination; residual (offr = -1: none)
+  int32_t kg0, kg1, ntiles, act;           // 16-channel groups of each source, 16-channel output tiles, activation
+  int32_t w_lds, w_chunks;                 // 1: weights staged in LDS; 16-byte pieces of one column tile (taps x groups x 64)
+  int32_t w_slot, w_after_barrier;         // which weight buffer; 1: it is the buffer the previous layer reads (store after its barrier)
 };
+constexpr int FUSED_OP_WORDS = sizeof(FusedOp) / 4;
+constexpr int FUSED_LDS_OPS = 48;          // descriptors kept in LDS (more layers: read from memory per layer)
 struct FusedProgram {
-  int32_t n_ops, hw, h, wd, policy_buf, value_buf, planes, hex;
-  int32_t zrow_off, wbuf_off;              // float offsets of the zero row and of the weight buffer in LDS
-  int32_t buf_off[FUSED_BUFFERS];          // float offset of each buffer in LDS
-  int32_t buf_cs[FUSED_BUFFERS];           // floats per row (channels + FUSED_PAD)
+  int32_t n_ops, hw, h, wd, planes, hex;
+  int32_t zrow_off, ops_off;               // float offsets of the zero row and of the descriptors' copy (-1: none) in LDS
+  int32_t wbuf_off[2];                     // the two weight buffers (the second may be the input rows' space, or the first again)
+  int32_t in_off, in_cs, pol_off, pol_cs, val_off, val_cs;     // input rows, policy logits, value plane
   FusedOp ops[FUSED_MAX_OPS];
 };
 
@@ -499,19 +503,20 @@ typedef const __attribute__((address_space(1))) f32x4* gptr4;
 // [col tile][NTAPS + 1][kg][lane][4]: piece i of 16 bytes, i = tid + 1024 j.
 template <int NTAPS>
 __device__ __forceinline__ void fetch_weights(const FusedOp& op, f32x4 (&wreg)[FUSED_WREGS], int tid) {
-  const int kgt = op.kg0 + op.kg1, per_tile = NTAPS * kgt * 64, total = op.ntiles * per_tile;
+  const int kgt = op.kg0 + op.kg1, per_tile = op.w_chunks, total = op.ntiles * per_tile;
 #pragma unroll
   for (int j = 0; j < FUSED_WREGS; ++j) {
     const int i = tid + j * FUSED_THREADS;
     if (i < total) {
-      const int ct = i / per_tile, within = i - ct * per_tile;
+      int ct = 0, within = i;                  // (at most a handful of column tiles: no division)
+      while (within >= per_tile) { within -= per_tile; ++ct; }
       wreg[j] = *((gptr4)op.w + (size_t)ct * ((NTAPS + 1) * kgt * 64) + within);
     }
   }
 }
 template <int NTAPS>
 __device__ __forceinline__ void store_weights(const FusedOp& op, float* wbuf, const f32x4 (&wreg)[FUSED_WREGS], int tid) {
-  const int kgt = op.kg0 + op.kg1, total = op.ntiles * NTAPS * kgt * 64;
+  const int total = op.ntiles * op.w_chunks;
 #pragma unroll
   for (int j = 0; j < FUSED_WREGS; ++j) {
     const int i = tid + j * FUSED_THREADS;
@@ -574,12 +579,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
   const int p0 = blockIdx.x * P;
   if (p0 >= n_pos) return;                                  // uniform per workgroup
   const int np = min(P, n_pos - p0);
-  const int hw = prog->hw, H = prog->h, Wd = prog->wd;
+  const int hw = prog->hw, H = prog->h, Wd = prog->wd, n_ops = prog->n_ops;
+#ifdef NZ_FUSED_STAMPS     // diagnostic build: where one workgroup's time goes (printed by workgroup 0)
+  unsigned long long tk_in = 0, tk_job[32], tk_bar[32], tk_fin = 0, ts = __builtin_amdgcn_s_memtime();
+#define FSTAMP(x) { const unsigned long long now = __builtin_amdgcn_s_memtime(); x = now - ts; ts = now; }
+#else
+#define FSTAMP(x)
+#endif
   const int rows = np * hw, row_tiles = (rows + 15) >> 4;
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int q4 = (lane >> 4) * 4;
+  const int zoff = prog->zrow_off;
 
   {   // this workgroup's input rows -> LDS buffer 0 (global row of (position n, cell c): ((n >> 4) * hw + c) * 16 + (n & 15))
-    const int cs = prog->buf_cs[0];
-    float* dst = lds + prog->buf_off[0];
+    const int cs = prog->in_cs;
+    float* dst = lds + prog->in_off;
     const int chunks = in_channels >> 2;                    // 16-byte pieces per row
     for (int i = tid; i < rows * chunks; i += FUSED_THREADS) {
       const int r = i / chunks, c4 = (i - r * chunks) << 2;
@@ -588,56 +602,79 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
       *reinterpret_cast<f32x4*>(dst + r * cs + c4) = *reinterpret_cast<const f32x4*>(in_rows + grow * in_channels + c4);
     }
   }
+  // the layer descriptors -> LDS (a scalar load chain per layer otherwise), the row of zeros an off-board tap reads
+  uint32_t* const sops = reinterpret_cast<uint32_t*>(lds + prog->ops_off);
+  const bool ops_in_lds = prog->ops_off >= 0;
+  if (ops_in_lds)
+    for (int i = tid; i < n_ops * FUSED_OP_WORDS; i += FUSED_THREADS) sops[i] = reinterpret_cast<const uint32_t*>(prog->ops)[i];
+  for (int i = tid; i < FUSED_ZROW; i += FUSED_THREADS) lds[zoff + i] = 0.f;
+  auto load_op = [&](int o) {
+    FusedOp op;
+    if (ops_in_lds) {
+      uint32_t w[FUSED_OP_WORDS];
+#pragma unroll
+      for (int i = 0; i < FUSED_OP_WORDS; ++i) w[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)sops[o * FUSED_OP_WORDS + i]);
+      __builtin_memcpy(&op, w, sizeof(op));
+    } else {
+      op = prog->ops[o];
+    }
+    return op;
+  };
+  if (n_ops > 0 && prog->ops[0].w_lds) stage_weights<ntaps>(prog->ops[0], lds + prog->wbuf_off[prog->ops[0].w_slot], tid, true);
   __syncthreads();
+  FSTAMP(tk_in);
 
-  constexpr int ntaps = HEX ? 7 : 9;
-  const int q4 = (lane >> 4) * 4;
-  float* const wbuf = lds + prog->wbuf_off;                 // this layer's weights, when they fit (FusedOp::w_lds)
-  for (int i = tid; i < FUSED_ZROW; i += FUSED_THREADS) lds[prog->zrow_off + i] = 0.f;   // what an off-board tap reads
-  if (prog->n_ops > 0 && prog->ops[0].w_lds) stage_weights<ntaps>(prog->ops[0], wbuf, tid, true);
-  __syncthreads();
-
-  for (int o = 0; o < prog->n_ops; ++o) {
-    const FusedOp op = prog->ops[o];
+  // this lane's operand rows per tap, relative to a buffer: recomputed only when the wave's row tile changes
+  int rt_cached = -1, srow[ntaps];
+  uint32_t on_mask = 0;
+  FusedOp next = n_ops > 0 ? load_op(0) : FusedOp{};
+  for (int o = 0; o < n_ops; ++o) {
+    const FusedOp op = next;
+    if (o + 1 < n_ops) next = load_op(o + 1);
     // the NEXT layer's weights start their way from L2 now and are parked in registers under this layer's MFMAs
-    const bool next_lds = o + 1 < prog->n_ops && prog->ops[o + 1].w_lds;
+    const bool next_lds = o + 1 < n_ops && next.w_lds;
     f32x4 wreg[FUSED_WREGS];
-    if (next_lds) fetch_weights<ntaps>(prog->ops[o + 1], wreg, tid);
-    const int off0 = prog->buf_off[op.src0], cs0 = prog->buf_cs[op.src0];
-    const int off1 = op.src1 >= 0 ? prog->buf_off[op.src1] : off0, cs1 = op.src1 >= 0 ? prog->buf_cs[op.src1] : cs0;
-    float* dst = lds + prog->buf_off[op.dst];
-    const int csd = prog->buf_cs[op.dst];
-    const float* res = op.res >= 0 ? lds + prog->buf_off[op.res] : nullptr;
-    const int csr = op.res >= 0 ? prog->buf_cs[op.res] : 0;
+    if (next_lds) fetch_weights<ntaps>(next, wreg, tid);
+    float* dst = lds + op.offd;
+    const float* res = op.offr >= 0 ? lds + op.offr : nullptr;
     const int kg0 = op.kg0, kgt = op.kg0 + op.kg1;
     const size_t tile_stride = (size_t)(ntaps + 1) * kgt * 256;
     const int n_jobs = row_tiles * op.ntiles;
+    const float* wbuf = lds + prog->wbuf_off[op.w_slot];
     for (int job = wave; job < n_jobs; job += FUSED_WAVES) {
       const int rt = job / op.ntiles, ct = job - rt * op.ntiles;
-      const int row = rt * 16 + (lane & 15);
-      const bool row_ok = row < rows;
-      const int pl = row / hw, cell = row - pl * hw;
-      const int cy = cell / Wd, cx = cell - cy * Wd;
+      if (rt != rt_cached) {
+        rt_cached = rt;
+        const int row = rt * 16 + (lane & 15);
+        const bool row_ok = row < rows;
+        const int pl = row / hw, cell = row - pl * hw;
+        const int cy = cell / Wd, cx = cell - cy * Wd;
+        on_mask = 0;
+#pragma unroll
+        for (int tap = 0; tap < ntaps; ++tap) {
+          const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+          const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+          if (row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd) on_mask |= 1u << tap;
+          srow[tap] = row + dy * Wd + dx;
+        }
+      }
       // per tap: where this lane's operand row starts in LDS (float index); off the board -> the row of zeros
       int aoff0[ntaps], aoff1[ntaps];
 #pragma unroll
       for (int tap = 0; tap < ntaps; ++tap) {
-        const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
-        const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
-        const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
-        const int srow = row + dy * Wd + dx;
-        aoff0[tap] = on ? off0 + srow * cs0 + q4 : prog->zrow_off + q4;
-        aoff1[tap] = on ? off1 + srow * cs1 + q4 : prog->zrow_off + q4;
+        const bool on = (on_mask >> tap) & 1u;
+        aoff0[tap] = on ? op.off0 + srow[tap] * op.cs0 + q4 : zoff + q4;
+        aoff1[tap] = on && op.off1 >= 0 ? op.off1 + srow[tap] * op.cs1 + q4 : zoff + q4;
       }
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const float* wl = wbuf + (size_t)ct * (ntaps * kgt * 256) + lane * 4;        // LDS copy: [ct][tap][kg][lane][4]
       const float* wg = op.w + (size_t)ct * tile_stride + lane * 4;                // packed stream in L2
-      if (op.src1 < 0 && op.w_lds && kgt == 2) conv_job<ntaps, 2, true>(acc, lds, aoff0, wl, wg);
-      else if (op.src1 < 0 && op.w_lds && kgt == 1) conv_job<ntaps, 1, true>(acc, lds, aoff0, wl, wg);
-      else if (op.src1 < 0 && op.w_lds && kgt == 3) conv_job<ntaps, 3, true>(acc, lds, aoff0, wl, wg);
-      else if (op.src1 < 0 && op.w_lds && kgt == 4) conv_job<ntaps, 4, true>(acc, lds, aoff0, wl, wg);
-      else if (op.src1 < 0 && kgt == 6) conv_job<ntaps, 6, false>(acc, lds, aoff0, wl, wg);
-      else if (op.src1 < 0 && kgt == 2) conv_job<ntaps, 2, false>(acc, lds, aoff0, wl, wg);
+      if (op.off1 < 0 && op.w_lds && kgt == 2) conv_job<ntaps, 2, true>(acc, lds, aoff0, wl, wg);
+      else if (op.off1 < 0 && op.w_lds && kgt == 1) conv_job<ntaps, 1, true>(acc, lds, aoff0, wl, wg);
+      else if (op.off1 < 0 && op.w_lds && kgt == 3) conv_job<ntaps, 3, true>(acc, lds, aoff0, wl, wg);
+      else if (op.off1 < 0 && op.w_lds && kgt == 4) conv_job<ntaps, 4, true>(acc, lds, aoff0, wl, wg);
+      else if (op.off1 < 0 && kgt == 6) conv_job<ntaps, 6, false>(acc, lds, aoff0, wl, wg);
+      else if (op.off1 < 0 && kgt == 2) conv_job<ntaps, 2, false>(acc, lds, aoff0, wl, wg);
       else conv_job_generic<ntaps>(acc, lds, aoff0, aoff1, kg0, kgt, op.w_lds ? wl : wg);
       const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
 #pragma unroll
@@ -645,48 +682,76 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
         const int orow = rt * 16 + r4 + r;
         if (orow < rows) {
           float v = acc[r];
-          if (res) v += res[orow * csr + col];
-          dst[orow * csd + col] = activate(v, op.act);
+          if (res) v += res[orow * op.csr + col];
+          dst[orow * op.csd + col] = activate(v, op.act);
         }
       }
     }
-    __syncthreads();                        // the layer's outputs are complete; nobody reads wbuf any more
-    if (next_lds) {
-      store_weights<ntaps>(prog->ops[o + 1], wbuf, wreg, tid);
+#ifdef NZ_FUSED_STAMPS
+    if (o < 32) FSTAMP(tk_job[o]);
+#endif
+    // The next layer's weights go to LDS: into the OTHER weight buffer right away when there is one (it was last
+    // read a layer ago), otherwise into the same one once every wave is done with it.  One barrier ends the layer.
+    if (next_lds && !next.w_after_barrier) store_weights<ntaps>(next, lds + prog->wbuf_off[next.w_slot], wreg, tid);
+    __syncthreads();
+    if (next_lds && next.w_after_barrier) {
+      store_weights<ntaps>(next, lds + prog->wbuf_off[next.w_slot], wreg, tid);
       __syncthreads();
     }
+#ifdef NZ_FUSED_STAMPS
+    if (o < 32) FSTAMP(tk_bar[o]);
+#endif
   }
 
-  // softmax over ALL logits (Explorer.py:159), value = tanh(mean) (blocks.py:82-84): finalize_kernel's arithmetic
-  const float* pol = lds + prog->buf_off[prog->policy_buf];
-  const int pp = prog->buf_cs[prog->policy_buf];
-  const float* val = lds + prog->buf_off[prog->value_buf];
-  const int vp = prog->buf_cs[prog->value_buf];
+  // softmax over ALL logits (Explorer.py:159), value = tanh(mean) (blocks.py:82-84): finalize_kernel's arithmetic in
+  // finalize_kernel's order (lane i sums actions i, i + 64, ...), one wavefront per position; exp() is kept in LDS
+  // between the passes so that the probabilities are written once
+  float* pol = lds + prog->pol_off;
+  const int pp = prog->pol_cs;
+  const float* val = lds + prog->val_off;
+  const int vp = prog->val_cs;
   const int A = prog->planes * hw;
+  const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
   for (int pl = wave; pl < np; pl += FUSED_WAVES) {
     const size_t n = (size_t)(p0 + pl);
+    float* prow = pol + pl * hw * pp;
     float mx = -INFINITY;
-    for (int i = lane; i < A; i += 64) {
-      const float v = pol[(pl * hw + i % hw) * pp + i / hw];
+    for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+      const float v = prow[cell * pp + plane];
       if (logits) logits[n * A + i] = v;
       mx = fmaxf(mx, v);
+      cell += dcell; plane += dplane;
+      if (cell >= hw) { cell -= hw; ++plane; }
     }
     for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w));
     if (probs) {
       float sum = 0.f;
-      for (int i = lane; i < A; i += 64) {
-        const float e = expf(pol[(pl * hw + i % hw) * pp + i / hw] - mx);
-        probs[n * A + i] = e;
+      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+        const float e = expf(prow[cell * pp + plane] - mx);
+        prow[cell * pp + plane] = e;
         sum += e;
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
       }
       for (int w = 32; w; w >>= 1) sum += __shfl_xor(sum, w);
-      for (int i = lane; i < A; i += 64) probs[n * A + i] /= sum;
+      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+        probs[n * A + i] = prow[cell * pp + plane] / sum;
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
+      }
     }
     float sv = 0.f;
     for (int c = lane; c < hw; c += 64) sv += val[(pl * hw + c) * vp];
     for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w);
     if (lane == 0) value[n] = tanhf(sv / (float)hw);
   }
+#ifdef NZ_FUSED_STAMPS
+  FSTAMP(tk_fin);
+  if (blockIdx.x == 0 && (tid == 0 || tid == FUSED_THREADS - 64)) {
+    printf("fused wg0 wave %d np %d rows %d: input %llu finalize %llu\n", wave, np, rows, tk_in, tk_fin);
+    for (int o = 0; o < n_ops && o < 32; ++o) printf("  wave %d op %d kgt %d ntiles %d wlds %d slot %d after %d: jobs %llu barrier+stage %llu\n", wave, o, prog->ops[o].kg0 + prog->ops[o].kg1, prog->ops[o].ntiles, prog->ops[o].w_lds, prog->ops[o].w_slot, prog->ops[o].w_after_barrier, tk_job[o], tk_bar[o]);
+  }
+#endif
 }
 
 struct ConvOp {
@@ -918,40 +983,79 @@ void build_fused(nz_boardnet* h, int trunk_out) {
     if (h->buffer_channels[b] > h->buffer_channels[alias[b]]) return;      // cannot happen: the value head narrows
   FusedProgram pg;
   memset(&pg, 0, sizeof(pg));
+  int buf_off[FUSED_BUFFERS], buf_cs[FUSED_BUFFERS];
   size_t off = 0;
   pg.zrow_off = 0;
   off += FUSED_ZROW;
   for (int b = 0; b < FUSED_BUFFERS; ++b) {
     if (alias[b] != b) continue;
-    pg.buf_off[b] = (int32_t)off;
-    pg.buf_cs[b] = h->buffer_channels[b] + FUSED_PAD;
-    off += (size_t)rows_max * pg.buf_cs[b];
+    buf_off[b] = (int)off;
+    buf_cs[b] = h->buffer_channels[b] + FUSED_PAD;
+    off += (size_t)rows_max * buf_cs[b];
   }
   for (int b = 0; b < FUSED_BUFFERS; ++b)
-    if (alias[b] != b) { pg.buf_off[b] = pg.buf_off[alias[b]]; pg.buf_cs[b] = pg.buf_cs[alias[b]]; }
+    if (alias[b] != b) { buf_off[b] = buf_off[alias[b]]; buf_cs[b] = buf_cs[alias[b]]; }
+  const int n_ops = (int)h->ops.size();
+  pg.ops_off = -1;
+  if (n_ops <= FUSED_LDS_OPS) { pg.ops_off = (int32_t)off; off += (size_t)n_ops * FUSED_OP_WORDS; off = (off + 3) / 4 * 4; }
   const size_t budget = 156 * 1024 / sizeof(float);      // 160 KB of LDS per CU
   if (off > budget) return;
-  pg.n_ops = (int32_t)h->ops.size();
+  pg.n_ops = n_ops;
   pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
-  pg.policy_buf = h->policy_buf; pg.value_buf = h->value_buf;
   pg.planes = h->net.policy_channels; pg.hex = h->net.hex ? 1 : 0;
+  pg.in_off = buf_off[0]; pg.in_cs = buf_cs[0];
+  pg.pol_off = buf_off[h->policy_buf]; pg.pol_cs = buf_cs[h->policy_buf];
+  pg.val_off = buf_off[h->value_buf]; pg.val_cs = buf_cs[h->value_buf];
   const int ntaps = h->net.hex ? 7 : 9;
   // layers whose weights fit in what is left of LDS (and in the registers that carry them there) are staged
   const size_t w_cap = std::min(budget - off, (size_t)FUSED_WREGS * FUSED_THREADS * 4);
   size_t wbuf = 0;
-  for (size_t i = 0; i < h->ops.size(); ++i) {
+  int last_input_reader = -1;
+  for (int i = 0; i < n_ops; ++i) {
     const ConvOp& op = h->ops[i];
     const PackedConv& pc = h->convs[i];
     FusedOp& f = pg.ops[i];
-    f.src0 = op.src0; f.src1 = op.src1; f.res = op.res; f.dst = op.dst;
+    f.w = pc.dev;
+    f.off0 = buf_off[op.src0]; f.cs0 = buf_cs[op.src0];
+    f.off1 = op.src1 >= 0 ? buf_off[op.src1] : -1; f.cs1 = op.src1 >= 0 ? buf_cs[op.src1] : 0;
+    f.offd = buf_off[op.dst]; f.csd = buf_cs[op.dst];
+    f.offr = op.res >= 0 ? buf_off[op.res] : -1; f.csr = op.res >= 0 ? buf_cs[op.res] : 0;
     f.kg0 = pc.c0p / 16; f.kg1 = op.src1 >= 0 ? pc.c1p / 16 : 0;
-    f.ntiles = pc.coutp / 16; f.act = op.act; f.w = pc.dev;
-    const size_t wf = (size_t)f.ntiles * ntaps * (f.kg0 + f.kg1) * 256;
+    f.ntiles = pc.coutp / 16; f.act = op.act;
+    f.w_chunks = ntaps * (f.kg0 + f.kg1) * 64;
+    const size_t wf = (size_t)f.ntiles * f.w_chunks * 4;
     f.w_lds = wf <= w_cap ? 1 : 0;
     if (f.w_lds) wbuf = std::max(wbuf, wf);
+    if (op.src0 == 0 || op.src1 == 0) last_input_reader = i;
   }
-  pg.wbuf_off = (int32_t)off;
+  pg.wbuf_off[0] = (int32_t)off;
   off += wbuf;
+  // a second weight buffer lets a layer's weights be written while the previous layer still reads its own: the input
+  // rows' space once no later layer reads the input (feed-forward nets), else whatever LDS is left, else none
+  int second_from = n_ops;                    // first layer index that may USE the second buffer
+  pg.wbuf_off[1] = pg.wbuf_off[0];
+  if (off + wbuf <= budget) {
+    pg.wbuf_off[1] = (int32_t)off;
+    off += wbuf;
+    second_from = 0;
+  } else if ((size_t)rows_max * buf_cs[0] >= wbuf) {
+    pg.wbuf_off[1] = buf_off[0];
+    second_from = last_input_reader + 2;      // its weights are stored during the layer before it
+  }
+  int slot = 0;
+  bool first = true;
+  for (int i = 0; i < n_ops; ++i) {
+    FusedOp& f = pg.ops[i];
+    if (!f.w_lds) continue;
+    if (first) { f.w_slot = 0; f.w_after_barrier = 0; first = false; slot = 0; continue; }
+    // the previous staged layer may still be reading `slot` when this one's weights arrive (only if it is layer i - 1)
+    const bool prev_reads = i > 0 && pg.ops[i - 1].w_lds;
+    if (prev_reads && i >= second_from && pg.wbuf_off[1] != pg.wbuf_off[0]) { slot ^= 1; f.w_after_barrier = 0; }
+    else f.w_after_barrier = prev_reads ? 1 : 0;
+    // (the input rows' space can only be slot 1; before `second_from` everything stays in slot 0)
+    if (i < second_from) { slot = 0; f.w_after_barrier = prev_reads ? 1 : 0; }
+    f.w_slot = slot;
+  }
   const size_t bytes = off * sizeof(float);
   const hipError_t e = h->net.hex
       ? hipFuncSetAttribute((const void*)fused_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)

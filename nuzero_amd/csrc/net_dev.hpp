@@ -328,7 +328,6 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], unsigned
 template <int OMASK>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob& job, unsigned char* __restrict__ lds,
                                          int lane, int policy_channels, int n_valid, float* logits, float* value) {
-  const int pos = lane & 15, quad = lane >> 4;
   if (job.dst < NET_BUFFERS) {
     unsigned char* dst = lds + job.dst * ACT_BYTES;
     if (job.res >= 0) {
