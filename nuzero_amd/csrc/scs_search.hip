@@ -475,26 +475,45 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     int node = root, plen = 1;
     if (lane == 0) path[0] = root;
     bool bad = false;
-    while (nodes[node].n_children > 0) {
-      const SNode parent = nodes[node];
-      if (parent.visit >= p.tab_len || plen >= p.max_path) { bad = true; break; }
-      const double sq = p.sqrt_tab[parent.visit], cb = p.bias_tab[parent.visit];
-      const bool negate = parent.to_play == p.negate_player;
+    // One dependent load per level: the chosen child's record was read when it was scored, so the lane that holds it
+    // hands the four words the next level needs (visit count, first child, children count, to_play) to the wavefront
+    // (v_readlane: the winner is wave-uniform) instead of every level re-reading its parent from memory.
+    int par_visit, par_base, par_k, par_to_play;
+    {
+      const SNode r0 = nodes[root];
+      par_visit = r0.visit; par_base = r0.child_base; par_k = r0.n_children; par_to_play = r0.to_play;
+    }
+    while (par_k > 0) {
+      if (par_visit >= p.tab_len || plen >= p.max_path) { bad = true; break; }
+      const double sq = p.sqrt_tab[par_visit], cb = p.bias_tab[par_visit];
+      const bool negate = par_to_play == p.negate_player;
       double score = -INFINITY;
       int key = -1;
-      for (int j = lane; j < parent.n_children; j += 64) {       // one chunk of 64 children per round, usually one
-        const SNode c = nodes[parent.child_base + j];
+      int b_visit = 0, b_base = 0, b_k = 0, b_to_play = 0;        // this lane's best child so far
+      for (int j = lane; j < par_k; j += 64) {                     // one chunk of 64 children per round, usually one
+        const SNode c = nodes[par_base + j];
         const double sc = child_score(p, c, sq, cb, negate);
-        const int ky = ((int)c.action << 8) | j;                 // j < 256; children are in ascending action order
-        if (sc > score || (sc == score && ky > key)) { score = sc; key = ky; }
+        const int ky = ((int)c.action << 8) | j;                   // j < 256; children are in ascending action order
+        if (sc > score || (sc == score && ky > key)) {
+          score = sc; key = ky;
+          b_visit = c.visit; b_base = c.child_base; b_k = c.n_children; b_to_play = c.to_play;
+        }
       }
+      const int my_key = key;
       // max over (score, action): the larger action wins a tie (Explorer.py:100)
       for (int w = 32; w >= 1; w >>= 1) {
         const double os = __shfl_xor(score, w, 64);
         const int ok = __shfl_xor(key, w, 64);
         if (os > score || (os == score && ok > key)) { score = os; key = ok; }
       }
-      node = parent.child_base + (key & 0xff);
+      // the lane that scored the winner (keys are unique: they carry the child index)
+      const unsigned long long holders = __ballot(my_key == key);
+      const int wl = __builtin_amdgcn_readfirstlane(__ffsll((long long)holders) - 1);
+      node = par_base + (key & 0xff);
+      par_visit = __builtin_amdgcn_readlane(b_visit, wl);
+      par_base = __builtin_amdgcn_readlane(b_base, wl);
+      par_k = __builtin_amdgcn_readlane(b_k, wl);
+      par_to_play = __builtin_amdgcn_readlane(b_to_play, wl);
       if (lane == 0) path[plen] = node;
       scs_step_wave(R, sc, key >> 8, lane);
       ++plen;
