@@ -395,6 +395,13 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
 /* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
  * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
 nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);
+/* Evaluation matches on SCS (Testing/Agents/Generic/MctsAgent.py:28-39, Testing/Tester.py:46-121), as
+ * nz_engine_search / _apply / _last_actions for Tic-Tac-Toe: after a move's search (begin_move + select / expand until
+ * no leaf is left) nz_scs_search_apply plays actions_dev[g] (int32 [G]; NULL or -1: the search's own choice,
+ * like nz_scs_search_end_move), steps and re-roots; nz_scs_search_last_actions gives each game's latest action. */
+nz_status nz_scs_search_apply(nz_scs_search* h, const int32_t* actions_dev, const double* uniforms_dev, void* stream);
+nz_status nz_scs_search_last_actions(nz_scs_search* h, int32_t* actions_dev, void* stream);
+
 /* The reference's optional inference cache (Explorer.py:146-155; Utils/Caches/KeylessCache.py:24-160, DictCache.py:4-85;
  * handed to Gamer.play_game by AlphaZero.py:560-577) for nz_scs_search_play: one keyless hash table in HBM shared by the
  * games of the engine -- a leaf whose state was evaluated before takes (probs, value) from the table instead of the

@@ -619,7 +619,9 @@ __global__ void search_status_kernel(SearchParams p, int32_t* out) {
 }
 
 // select_action, records, step and re-rooting (Explorer.py:70-97,183-199; Gamer.py:71-79)
-__global__ void end_move_kernel(SearchParams p, const double* __restrict__ uniforms) {
+// `forced` (may be null): per game an action to play instead of the search's own choice, -1 = own choice -- the
+// opponent's move in MctsAgent.update_subtree (Testing/Agents/Generic/MctsAgent.py:35-39)
+__global__ void end_move_kernel(SearchParams p, const double* __restrict__ uniforms, const int32_t* __restrict__ forced) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= p.n_games) return;
   ScsState& real = p.real[g];
@@ -650,7 +652,10 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
 
   int mode = 0;
   double u3 = 0.0;
-  if (p.training) {
+  const int forced_action = forced ? forced[g] : -1;
+  if (forced_action >= 0) {
+    mode = 3;
+  } else if (p.training) {
     const double u1 = uniforms[g * 3], u2 = uniforms[g * 3 + 1];
     u3 = uniforms[g * 3 + 2];
     if (move < p.softmax_moves) mode = 1;
@@ -681,6 +686,15 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
     for (int j = 0; j < k; ++j) { run = j == 0 ? pv : run + pv; cdf[j] = run; }
     chosen_child = k - 1;
     for (int j = 0; j < k; ++j) if (cdf[j] / cdf[k - 1] > u3) { chosen_child = j; break; }
+  }
+  if (mode == 3) {
+    chosen_child = -1;
+    for (int j = 0; j < k; ++j)
+      if (nodes[root.child_base + j].action == forced_action) chosen_child = j;
+    if (chosen_child < 0) {                  // not a legal move of this position
+      atomicOr(p.error_flag, 8);
+      return;
+    }
   }
   const int action = nodes[root.child_base + chosen_child].action;
   p.rec_action[gm] = action;
@@ -782,7 +796,7 @@ nz_status check_flag(nz_scs_search* h, hipStream_t s) {
   S_HIP(h, hipMemcpyAsync(&f, h->p.error_flag, sizeof(f), hipMemcpyDeviceToHost, s));
   S_HIP(h, hipStreamSynchronize(s));
   if (f) return sfail(h, NZ_ERR_OVERFLOW, "device check failed (flag %d: 1 arena full, 2 visit table/path too short, "
-                                          "4 move ended before its search, 16 more legal actions than the bound computed at create, 32 game longer than that bound)", f);
+                                          "4 move ended before its search, 8 forced action is not legal, 16 more legal actions than the bound computed at create, 32 game longer than that bound)", f);
   return NZ_OK;
 }
 }  // namespace
@@ -990,10 +1004,39 @@ nz_status nz_scs_search_end_move(nz_scs_search* h, const double* uniforms_dev, v
   if (h->cfg.training && !uniforms_dev) return sfail(h, NZ_ERR_ARG, "training search needs uniforms");
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(end_move_kernel, dim3((h->n_games + 63) / 64), dim3(64), 0, s, h->p, uniforms_dev);
+  hipLaunchKernelGGL(end_move_kernel, dim3((h->n_games + 63) / 64), dim3(64), 0, s, h->p, uniforms_dev,
+                     (const int32_t*)nullptr);
   hipLaunchKernelGGL(compact_kernel, dim3(h->n_games), dim3(64), 0, s, h->p);
   S_HIP(h, hipGetLastError());
   return check_flag(h, s);
+}
+
+nz_status nz_scs_search_apply(nz_scs_search* h, const int32_t* actions_dev, const double* uniforms_dev, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  if (!actions_dev && h->cfg.training && !uniforms_dev) return sfail(h, NZ_ERR_ARG, "a training search choosing its own action needs uniforms");
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(end_move_kernel, dim3((h->n_games + 63) / 64), dim3(64), 0, s, h->p, uniforms_dev, actions_dev);
+  hipLaunchKernelGGL(compact_kernel, dim3(h->n_games), dim3(64), 0, s, h->p);
+  S_HIP(h, hipGetLastError());
+  return check_flag(h, s);
+}
+
+namespace {
+__global__ void scs_last_actions_kernel(SearchParams p, int32_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games) return;
+  const int n = p.real[g].length;
+  out[g] = n > 0 && n <= p.max_moves ? p.rec_action[(size_t)g * p.max_moves + n - 1] : -1;
+}
+}  // namespace
+
+nz_status nz_scs_search_last_actions(nz_scs_search* h, int32_t* actions_dev, void* stream) {
+  if (!h || !actions_dev) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  hipLaunchKernelGGL(scs_last_actions_kernel, dim3((h->n_games + 127) / 128), dim3(128), 0, (hipStream_t)stream, h->p, actions_dev);
+  S_HIP(h, hipGetLastError());
+  return NZ_OK;
 }
 
 nz_status nz_scs_search_status(nz_scs_search* h, int32_t* status_dev, void* stream);

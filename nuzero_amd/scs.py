@@ -250,6 +250,41 @@ class ScsSelfPlay:
             self._check(lib.nz_scs_search_end_move(self._h, c_void_p(uni_d.data_ptr()), self._stream()))
         return self.export()
 
+    # ---- one move at a time: evaluation matches (MctsAgent.choose_action / update_subtree, Tester.Test_using_agents) ----
+    def reset(self):
+        self._check(lib.nz_scs_search_reset(self._h, self._stream()))
+
+    def search(self, evaluator, noise=None):
+        """Root noise (training engines; float64 [G, MAX_CHILDREN]) and the move's simulations for every live game;
+        no action yet."""
+        noise_d = torch.as_tensor(noise, dtype=torch.float64).to(self.device).contiguous() if noise is not None else None
+        self._check(lib.nz_scs_search_begin_move(self._h, c_void_p(noise_d.data_ptr()) if noise_d is not None else None,
+                                                 self._stream()))
+        while True:
+            n = c_int32(0)
+            self._check(lib.nz_scs_search_select(self._h, c_void_p(self._images.data_ptr()),
+                                                 c_void_p(self._leaf_game.data_ptr()), byref(n), self._stream()))
+            if n.value == 0:
+                return
+            probs, values = evaluator(self._images[:n.value])
+            probs = torch.as_tensor(probs, dtype=torch.float32).to(self.device).contiguous()
+            values = torch.as_tensor(values, dtype=torch.float32).to(self.device).contiguous()
+            self.evaluations += n.value
+            self._check(lib.nz_scs_search_expand(self._h, c_void_p(probs.data_ptr()), c_void_p(values.data_ptr()),
+                                                 self._stream()))
+
+    def apply(self, actions=None, uniforms=None):
+        """Play `actions` (int32 [G]; None / -1 = the search's own choice), step and re-root."""
+        a = torch.as_tensor(actions, dtype=torch.int32).to(self.device).contiguous() if actions is not None else None
+        u = torch.as_tensor(uniforms, dtype=torch.float64).to(self.device).contiguous() if uniforms is not None else None
+        self._check(lib.nz_scs_search_apply(self._h, c_void_p(a.data_ptr()) if a is not None else None,
+                                            c_void_p(u.data_ptr()) if u is not None else None, self._stream()))
+
+    def last_actions(self):
+        out = torch.empty((self.n_games,), dtype=torch.int32, device=self.device)
+        self._check(lib.nz_scs_search_last_actions(self._h, c_void_p(out.data_ptr()), self._stream()))
+        return out
+
     def play_native(self, net, seeds, max_moves=None):
         """As play(), with the network on the device as well (`net`: nuzero_amd.boardnet.BoardNet with
         max_batch >= n_games): the whole move loop runs in the library (nz_scs_search_play), the

@@ -343,3 +343,56 @@ def test_scs_round_larger_than_the_concurrent_trees():
     for ra, rb_ in zip(out[10][0], out[4][0]):
         assert ra.length == rb_.length and ra.terminal_value == rb_.terminal_value and ra.child_policy == rb_.child_policy
     assert out[10][1] == out[4][1]
+
+
+@pytest.mark.parametrize("sims1,sims2", [(12, 20), (25, 9)])
+def test_scs_evaluation_match_between_two_mcts_agents(sims1, sims2):
+    """Tester.Test_using_agents with two MctsAgents that keep their subtrees, on SCS: two device engines
+    (training=False), both search every decision, the mover's action is applied to both (nz_scs_search_apply).
+    The action sequence equals oracle/agents.py (MctsAgent.py:28-39, Tester.py:62-118: agent 1 plays player index 1)."""
+    import torch
+    from scs_eval import evaluate_image
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from oracle.agents import MctsAgentRef, play_match
+    from oracle.scs import ScsConfig, ScsGame
+    path = os.path.join(GOLDEN, "scs_configs", "late_reinforcements_5x5.yml")
+    cfg, ocfg = ScsGameConfig(path), ScsConfig(path)
+    A = cfg.num_actions
+
+    def search_cfg(sims):
+        return {"Simulation": {"mcts_simulations": sims, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+                "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                                "epsilon_random_exploration": 0.001, "value_factor": 1,
+                                "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                                "root_dist_alpha": 0.15, "root_dist_beta": 1}}
+
+    def device_ev(images):
+        out = [evaluate_image(im, A) for im in images.cpu().numpy()]
+        return (torch.from_numpy(np.stack([o[0] for o in out])), torch.from_numpy(np.array([o[1] for o in out], np.float32)))
+
+    ev = lambda gm: evaluate_image(gm.state_image()[0], A)
+    game = ScsGame(ocfg)
+    want = play_match(game, MctsAgentRef(search_cfg(sims1), ev), MctsAgentRef(search_cfg(sims2), ev))
+    e1 = ScsSelfPlay(cfg, search_cfg(sims1), 2, training=False)
+    e2 = ScsSelfPlay(cfg, search_cfg(sims2), 2, training=False)
+    e1.reset(); e2.reset()
+    got = []
+    while e1.status()[0, 4] == 0:
+        player = int(e1.status()[0, 0])
+        mover, other = (e1, e2) if player == 1 else (e2, e1)
+        mover.search(device_ev)
+        other.search(device_ev)               # update_subtree: the opponent searches the same position
+        mover.apply()                          # choose_action (max_action)
+        a = mover.last_actions()
+        other.apply(actions=a)
+        got.append(int(a[0]))
+        assert int(a[0]) == int(a[1])
+    assert got == want
+    s1, s2 = e1.status(), e2.status()
+    assert np.array_equal(s1, s2) and s1[0, 5] == game.terminal_value and s1[0, 6] == game.length
+    from nuzero_amd._lib import NzError
+    e3 = ScsSelfPlay(cfg, search_cfg(4), 1, training=False)
+    e3.reset(); e3.search(device_ev)
+    with pytest.raises(NzError):              # an action that is not legal in the position
+        e3.apply(actions=[A - 1])
+    e1.close(); e2.close(); e3.close()
