@@ -214,7 +214,7 @@ def main():
 
     def step(i):
         # every game of every rank and round has its own stream seed
-        eng.play(base_seed=(i * world + rank) * n_round)
+        eng.play(base_seed=(i * world + rank) * n_round, next_base_seed=((i + 1) * world + rank) * n_round)
         if gather is not None:
             gather.gather()
 

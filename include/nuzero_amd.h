@@ -180,6 +180,10 @@ nz_status nz_engine_live_games(nz_engine* e, int32_t* n_live_host, void* stream)
  * (SURVEY.md appendix A rules 13-17).  Resets, then plays until every game is
  * terminal (Gamer.play_game, Gamer.py:39-97, for G games).  Synchronises. */
 nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream);
+/* As nz_engine_play; with have_next the random numbers of the round that will be played next (seeds
+ * next_base_seed + g) are drawn on the host threads while this round's kernel runs, and the next call with that
+ * base seed uses them (any other call draws afresh: results never depend on the hint). */
+nz_status nz_engine_play_next(nz_engine* e, uint64_t base_seed, int32_t have_next, uint64_t next_base_seed, void* stream);
 
 /* Same games, same results, by the lock-step route: one kernel sequence per move
  * with a host round trip in between (the route nz_engine_move exposes).

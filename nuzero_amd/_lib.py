@@ -76,6 +76,7 @@ SIGNATURES = {
     "nz_engine_move": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_engine_live_games": (c_int32, [c_void_p, POINTER(c_int32), c_void_p]),
     "nz_engine_play": (c_int32, [c_void_p, c_uint64, c_void_p]),
+    "nz_engine_play_next": (c_int32, [c_void_p, c_uint64, c_int32, c_uint64, c_void_p]),
     "nz_engine_play_lockstep": (c_int32, [c_void_p, c_uint64, c_void_p]),
     "nz_engine_desync_count": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_engine_export": (c_int32, [c_void_p] + [c_void_p] * 8 + [c_void_p]),

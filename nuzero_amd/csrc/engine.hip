@@ -61,6 +61,11 @@ struct nz_engine {
   double* d_game_noise = nullptr;
   double* d_game_uniforms = nullptr;
   int32_t* h_desync = nullptr;        // pinned [G]
+  // randomness of the NEXT round, drawn on host threads while this round's kernel runs (nz_engine_play_next)
+  double* h_next_noise = nullptr;     // pinned [G][T][A]
+  double* h_next_uniforms = nullptr;  // pinned [G][T][3]
+  bool next_ready = false;
+  uint64_t next_seed = 0;
   bool borrowed_net = false;          // fallback engine: network buffers belong to the parent
   nz_engine* fallback = nullptr;
   int64_t desync_total = 0;
@@ -365,12 +370,16 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
       hipHostMalloc((void**)&e->h_uniforms, G * 3 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&e->h_game_noise, GTA * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&e->h_game_uniforms, GT * 3 * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_next_noise, GTA * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&e->h_next_uniforms, GT * 3 * sizeof(double)) != hipSuccess ||
       hipHostMalloc((void**)&e->h_desync, G * sizeof(int32_t)) != hipSuccess)
     return bail(fail(e, NZ_ERR_HIP, "pinned host allocation failed"));
   memset(e->h_noise, 0, G * TTT_ACTIONS * sizeof(double));
   memset(e->h_uniforms, 0, G * 3 * sizeof(double));
   memset(e->h_game_noise, 0, GTA * sizeof(double));
   memset(e->h_game_uniforms, 0, GT * 3 * sizeof(double));
+  memset(e->h_next_noise, 0, GTA * sizeof(double));
+  memset(e->h_next_uniforms, 0, GT * 3 * sizeof(double));
 
   launch_reset(p, nullptr);
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, NZ_ERR_HIP, "reset kernel failed"));
@@ -389,6 +398,8 @@ void nz_engine_destroy(nz_engine* e) {
   if (e->h_game_noise) (void)hipHostFree(e->h_game_noise);
   if (e->h_game_uniforms) (void)hipHostFree(e->h_game_uniforms);
   if (e->h_desync) (void)hipHostFree(e->h_desync);
+  if (e->h_next_noise) (void)hipHostFree(e->h_next_noise);
+  if (e->h_next_uniforms) (void)hipHostFree(e->h_next_uniforms);
   if (e->h_children) (void)hipHostFree(e->h_children);
   if (e->h_alive) (void)hipHostFree(e->h_alive);
   if (e->h_noise) (void)hipHostFree(e->h_noise);
@@ -791,7 +802,35 @@ static nz_status replay_desynced(nz_engine* e, const std::vector<int>& games, ui
   return NZ_OK;
 }
 
+// every game's draws for a whole round into (noise [G][T][A], uniforms [G][T][3]), assuming the root of move m >= 1
+// has 9 - m children (selfplay.hip); games are dealt to host threads
+static void draw_round(nz_engine* e, uint64_t base_seed, double* noise, double* uniforms) {
+  const int G = e->n_games;
+  const nz_search_cfg& c = e->cfg;
+  const int n_threads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+  auto work = [&](int t) {
+    for (int g = t; g < G; g += n_threads) {
+      nz_rng* r = e->rngs[g];
+      nz_rng_seed(r, (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu));
+      for (int m = 0; m < TTT_MAX_MOVES; ++m)
+        draw_move(r, c, m, m == 0 ? 0 : TTT_ACTIONS - m, noise + ((size_t)g * TTT_MAX_MOVES + m) * TTT_ACTIONS,
+                  uniforms + ((size_t)g * TTT_MAX_MOVES + m) * 3);
+    }
+  };
+  if (G < 256 || n_threads == 1) {
+    for (int t = 0; t < n_threads; ++t) work(t);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
+    for (auto& th : pool) th.join();
+  }
+}
+
 nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
+  return nz_engine_play_next(e, base_seed, 0, 0, stream);
+}
+
+nz_status nz_engine_play_next(nz_engine* e, uint64_t base_seed, int32_t have_next, uint64_t next_base_seed, void* stream) {
   if (!e) return NZ_ERR_ARG;
   if (!e->have_net && !e->have_table) return fail(e, NZ_ERR_STATE, "no network: call nz_engine_set_weights first");
   NZ_HIP(e, hipSetDevice(e->device));
@@ -802,27 +841,15 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
   nz_status st = nz_engine_reset(e, stream);
   if (st != NZ_OK) return st;
   if (c.training) {
-    // whole-game draws, assuming the root of move m >= 1 has 9 - m children (selfplay.hip)
     ensure_rngs(e);
-    const int n_threads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-    auto work = [&](int t) {
-      for (int g = t; g < G; g += n_threads) {
-        nz_rng* r = e->rngs[g];
-        nz_rng_seed(r, (uint32_t)((base_seed + (uint64_t)g) & 0xffffffffu));
-        for (int m = 0; m < TTT_MAX_MOVES; ++m)
-          draw_move(r, c, m, m == 0 ? 0 : TTT_ACTIONS - m,
-                    e->h_game_noise + ((size_t)g * TTT_MAX_MOVES + m) * TTT_ACTIONS,
-                    e->h_game_uniforms + ((size_t)g * TTT_MAX_MOVES + m) * 3);
-      }
-    };
-    if (G < 256 || n_threads == 1) {
-      for (int t = 0; t < n_threads; ++t) work(t);
-    } else {
-      std::vector<std::thread> pool;
-      for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
-      for (auto& th : pool) th.join();
-    }
     const size_t GT = (size_t)G * TTT_MAX_MOVES;
+    if (e->next_ready && e->next_seed == base_seed) {      // drawn under the previous round's kernel
+      std::swap(e->h_game_noise, e->h_next_noise);
+      std::swap(e->h_game_uniforms, e->h_next_uniforms);
+    } else {
+      draw_round(e, base_seed, e->h_game_noise, e->h_game_uniforms);
+    }
+    e->next_ready = false;
     NZ_HIP(e, hipMemcpyAsync(e->d_game_noise, e->h_game_noise, GT * TTT_ACTIONS * sizeof(double), hipMemcpyHostToDevice, s));
     NZ_HIP(e, hipMemcpyAsync(e->d_game_uniforms, e->h_game_uniforms, GT * 3 * sizeof(double), hipMemcpyHostToDevice, s));
   }
@@ -833,6 +860,11 @@ nz_status nz_engine_play(nz_engine* e, uint64_t base_seed, void* stream) {
                     e->stamps ? e->d_stamps : nullptr, s);
   }
   NZ_HIP(e, hipGetLastError());
+  if (c.training && have_next) {                            // the next round's draws, while the kernel runs
+    draw_round(e, next_base_seed, e->h_next_noise, e->h_next_uniforms);
+    e->next_ready = true;
+    e->next_seed = next_base_seed;
+  }
   st = check_device_flag(e, s);
   if (st != NZ_OK) return st;
   if (c.training) {

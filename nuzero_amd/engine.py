@@ -184,11 +184,15 @@ class SelfPlayEngine:
             check(lib.nz_engine_live_games(self._h, byref(n), _stream()), self._h)
         return n.value
 
-    def play(self, base_seed=0):
+    def play(self, base_seed=0, next_base_seed=None):
         """Reset and play every game to the end with the engine's own host
-        random streams (game g <- RandomState(base_seed + g))."""
+        random streams (game g <- RandomState(base_seed + g)).  `next_base_seed`: the seed of the round that will
+        be played next -- its random numbers are drawn on the host while this round's kernel runs."""
         with torch.cuda.device(self.device):
-            check(lib.nz_engine_play(self._h, int(base_seed), _stream()), self._h)
+            if next_base_seed is None:
+                check(lib.nz_engine_play(self._h, int(base_seed), _stream()), self._h)
+            else:
+                check(lib.nz_engine_play_next(self._h, int(base_seed), 1, int(next_base_seed), _stream()), self._h)
 
     def play_lockstep(self, base_seed=0):
         """Same results as play() by the lock-step route (one launch sequence per move)."""

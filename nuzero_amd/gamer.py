@@ -205,7 +205,7 @@ class Gamer:
             if self.cache_choice != "disabled":
                 self.engine.cache_all_positions()
             self._loaded = (id(nm), nm.version)
-        self.engine.play(base_seed=self.base_seed)
+        self.engine.play(base_seed=self.base_seed, next_base_seed=self.base_seed + self.num_games)
         self.base_seed += self.num_games
         on_device = hasattr(self.buffer, "save_games_from_engine")
         if on_device:

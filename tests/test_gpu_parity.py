@@ -629,3 +629,19 @@ def test_baseline_config_3_share_of_one_gpu_equals_c_oracle():
     assert c["simulations"] == o["simulations"] == int(r["lengths"].sum()) * 400 and c["expansions"] == o["expansions"]
     assert (r["tree_size"][:, 0] == 400).all()
     eng.close()
+
+
+def test_next_round_randomness_drawn_ahead_changes_nothing(search_kat, net_kat):
+    """nz_engine_play_next draws the next round's random numbers while the kernel runs: the round played from them equals
+    the reference's games, whether the hint was right, wrong or absent."""
+    case = search_kat["explore50_B"]
+    games = case["games"]
+    base = games[0]["seed"]
+    eng = _engine(case["config"], len(games), training=True)
+    eng.set_table(full_table(net_kat, case["table"]))
+    eng.play(base_seed=base + 1000, next_base_seed=base)          # some other round first; hint = the golden round
+    eng.play(base_seed=base, next_base_seed=base + 5)
+    _compare_with_reference_games(eng.export(trace=True), games)
+    eng.play(base_seed=base)                                     # prepared data for base + 5 is ignored
+    _compare_with_reference_games(eng.export(trace=True), games)
+    eng.close()
