@@ -2,6 +2,7 @@
 """Benchmark of the self-play hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--round R] [--sims S]
+    python bench.py --round 65536 --no-extras      # longer rounds on the same 4096 trees: less end-of-round tail
 
 A "step" is one self-play round on one GPU: R Tic-Tac-Toe games played to the
 end on G concurrent game trees (slots that finish a game take the next one, as
@@ -27,7 +28,6 @@ Extra keys (N = 1)
   phases            in-kernel shader-clock shares of the stamped diagnostic build
   scs_config4       BASELINE.json configs[3]: SCS 5x5, ConvNet(32 filters x 8 layers, square convs), 200 sims/move,
                     1024 concurrent games, one whole round in the library (nz_scs_search_play)
-  long_rounds       the same workload with 16 x (instead of 4 x) the concurrent games per round (less end-of-round tail)
   gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
                     save_game for every game, statistics), games/s
   cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
@@ -369,20 +369,6 @@ def main():
                                   "launches": big["launches"], "simulations_per_s": big["simulations_per_s"],
                                   "at_workload_trees": dict(sel[args.games], trees=args.games)}
         eng.close()
-        # ---- the same workload with longer rounds: a round ends with workgroups that have run out of games while
-        #      others still play (phases.mean_over_max_lifetime); 16 x the concurrent games per round amortises that tail
-        long_round = 16 * args.games
-        le = SelfPlayEngine(cfg, long_round, training=True, device=local_rank, n_slots=args.games)
-        le.set_weights(weights, recurrent_iterations=args.iters)
-        le.play(base_seed=3 * 10 ** 6, next_base_seed=3 * 10 ** 6 + long_round)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        le.play(base_seed=3 * 10 ** 6 + long_round, next_base_seed=3 * 10 ** 6 + 2 * long_round)
-        le.play(base_seed=3 * 10 ** 6 + 2 * long_round)
-        torch.cuda.synchronize()
-        out["long_rounds"] = {"value": 2 * long_round / (time.perf_counter() - t1), "unit": "games/s",
-                              "games_per_round": long_round, "concurrent_games": args.games, "rounds": 2}
-        le.close()
         # ---- the reference-shaped surface and one SCS configuration, driver-timed
         out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
         out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
