@@ -136,7 +136,7 @@ struct NetJob {
   int8_t stage_end;    // 1: workgroup barrier after this job
   int8_t pad;
 };
-constexpr int NET_WAVES_HOST = 4;
+constexpr int NET_WAVES_HOST = 8;
 constexpr int NET_MAX_JOBS = 192;
 constexpr int OG_NONE = 7;
 struct NetProgram {

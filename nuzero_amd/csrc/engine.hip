@@ -193,20 +193,21 @@ PackedConv pack_conv(const float* w, int cout, int cin, int cin_main, std::vecto
 }
 
 // A stage of the network = convs that may run side by side.  Its units (conv, output tile,
-// output-cell group) are dealt to the four waves longest-first; every wave's last job of the
+// output-cell group) are dealt to the eight waves longest-first; every wave's last job of the
 // stage carries the barrier.
 struct StageConv {
   int tensor, src, dst, res, act;
-  bool split;   // cut each output tile into the four output-cell groups as well
+  bool split;   // each output tile may be cut into output-cell groups (halves or quarters) to give every wave a unit
 };
+const int og_taps[7] = {49, 13, 12, 12, 12, 26, 23};   // (input cell, tap) pairs per output-cell group (net_dev.hpp og_mask)
 bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::vector<StageConv>& stage) {
-  static const int og_taps[5] = {49, 13, 12, 12, 12};
   struct Unit { NetJob job; int cost; };
   std::vector<Unit> units;
   for (const StageConv& sc : stage) {
     const PackedConv& pc = convs[sc.tensor];
     for (int nt = 0; nt < pc.ntiles; ++nt) {
-      const int og_first = sc.split ? 1 : 0, og_last = sc.split ? 4 : 0;
+      const int pieces = !sc.split || pc.ntiles >= NET_WAVES_HOST ? 1 : 2 * pc.ntiles >= NET_WAVES_HOST ? 2 : 4;
+      const int og_first = pieces == 1 ? 0 : pieces == 2 ? 5 : 1, og_last = pieces == 1 ? 0 : pieces == 2 ? 6 : 4;
       for (int og = og_first; og <= og_last; ++og) {
         NetJob j{};
         j.w_off = pc.w_off + nt * pc.kgroups * NET_KG_DWORDS;
@@ -221,7 +222,7 @@ bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::
     }
   }
   std::stable_sort(units.begin(), units.end(), [](const Unit& a, const Unit& b) { return a.cost > b.cost; });
-  int load[NET_WAVES_HOST] = {0, 0, 0, 0};
+  int load[NET_WAVES_HOST] = {};
   int first[NET_WAVES_HOST];
   for (int w = 0; w < NET_WAVES_HOST; ++w) first[w] = pg.n_jobs[w];
   for (const Unit& u : units) {
@@ -493,16 +494,16 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
     ok = ok && add_stage(pg, convs, convs_in_stage);
   };
   if (arch == NZ_ARCH_CONVNET) {                                      // ConvNet.py:20-40: (conv, ELU) x (1 + num_layers)
-    stage({{0, 0, cur, -1, 3, false}});
-    for (int i = 1; i < trunk_tensors; ++i) { stage({{i, cur, cur ^ 1, -1, 3, false}}); cur ^= 1; }
+    stage({{0, 0, cur, -1, 3, true}});
+    for (int i = 1; i < trunk_tensors; ++i) { stage({{i, cur, cur ^ 1, -1, 3, true}}); cur ^= 1; }
   } else {
-    stage({{0, 0, cur, -1, 1, false}});                               // projection / input block + ReLU
+    stage({{0, 0, cur, -1, 1, true}});                                // projection / input block + ReLU
     const int first_block = recall ? 2 : 1;
     for (int it = 0; it < iterations; ++it) {
-      if (recall) { stage({{1, cur, cur ^ 1, -1, 0, false}}); cur ^= 1; }   // cat([thought, x]) conv, no activation
+      if (recall) { stage({{1, cur, cur ^ 1, -1, 0, true}}); cur ^= 1; }    // cat([thought, x]) conv, no activation
       for (int b = 0; b < net->num_blocks; ++b) {                         // relu(conv2(relu(conv1(t))) + t)
-        stage({{first_block + 2 * b, cur, cur ^ 1, -1, 1, false}});
-        stage({{first_block + 2 * b + 1, cur ^ 1, cur, cur, 1, false}});
+        stage({{first_block + 2 * b, cur, cur ^ 1, -1, 1, true}});
+        stage({{first_block + 2 * b + 1, cur ^ 1, cur, cur, 1, true}});
       }
     }
   }
@@ -529,7 +530,6 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   e->algorithmic_flops_per_position = flops;
   {   // what the matrix cores execute for one tile of 16 positions (net_dev.hpp): six bf16 MFMAs per
       // (input cell, tap) pair and 32-channel K group, one float32 MFMA per pair for the input planes
-    static const int og_taps[5] = {49, 13, 12, 12, 12};
     double bf16 = 0.0, f32 = 0.0;
     for (int w = 0; w < NET_WAVES_HOST; ++w)
       for (int j = 0; j < pg.n_jobs[w]; ++j) {

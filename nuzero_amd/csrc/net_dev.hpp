@@ -61,7 +61,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr int POS = 16;            // positions per workgroup (MFMA N)
 constexpr int CELLS = 9;
 constexpr int ROW = 64;            // channels per (cell, pos) row
-constexpr int NET_WAVES = 4;
+constexpr int NET_WAVES = 8;            // two wavefronts per SIMD: one's epilogue / operand loads run under the other's MFMAs
 constexpr int NET_THREADS = NET_WAVES * 64;
 constexpr int NET_BUFFERS = NET_ACT_BUFFERS;
 constexpr int PIECE_BYTES = CELLS * POS * ROW * 2;          // one bf16 piece of one buffer
@@ -70,13 +70,15 @@ constexpr int ACT_FLOATS = ACT_BYTES / 4;                   // LDS is declared a
 constexpr int INP_FLOATS = CELLS * POS * 4;
 constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
 constexpr int TAP_DWORDS = 3 * 64 * 4;                      // one tap of one K group: [piece][lane][8 bf16]
-constexpr int W_RING = 9;                                   // taps in flight: the weights run one whole K group ahead
+constexpr int W_RING = 3;                                   // taps in flight: the weight stream runs three taps ahead of the MFMAs
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
 static_assert(NET_KG_DWORDS == 9 * TAP_DWORDS && NET_KG_CHANNELS == 32, "host packing (engine.hip) and kernel agree");
 
-// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} (taps: 49 | 13, 12, 12, 12)
+// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} | two halves {0,1,2,3,5} {4,6,7,8}
+// ((input cell, tap) pairs: 49 | 13, 12, 12, 12 | 26, 23)
 __host__ __device__ constexpr int og_mask(int og) {
-  return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 : 0;
+  return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 :
+         og == 5 ? 0x02F : og == 6 ? 0x1D0 : 0;
 }
 
 // byte offset of the 16-byte slot holding channels 8 s .. 8 s + 7 of (cell, pos) inside one piece
@@ -181,10 +183,16 @@ __device__ __forceinline__ void load_tap(Pieces& t, const float* __restrict__ w,
   t.p[0] = t.p[1] = t.p[2] = u32x4{v, v, v, v};
   asm volatile("" :: "v"(w));
 #else
-  const u32x4* __restrict__ p = reinterpret_cast<const u32x4*>(w) + lane;
-  t.p[0] = p[0];
-  t.p[1] = p[64];
-  t.p[2] = p[128];
+  // uniform base + unsigned 32-bit lane offset: the loads take their base from scalar registers (no 64-bit address per
+  // tap).  The offset is opaque to the optimiser, which would otherwise fold it into a per-lane base outside the job loop.
+  unsigned off = (unsigned)lane * 16u;
+  asm volatile("" : "+v"(off));
+  typedef const __attribute__((address_space(1))) u32x4* gptr;   // global (not flat) loads: vmcnt only
+  unsigned long long b = reinterpret_cast<unsigned long long>(w);
+  asm volatile("" : "+s"(b));                              // the tap's base stays a scalar: base + lane offset + immediate
+  t.p[0] = *reinterpret_cast<gptr>(b + off);
+  t.p[1] = *reinterpret_cast<gptr>(b + off + 1024);
+  t.p[2] = *reinterpret_cast<gptr>(b + off + 2048);
 #endif
 }
 __device__ __forceinline__ void load_b(FragS& f, const float* __restrict__ w, int lane) {   // a whole K group
@@ -198,33 +206,34 @@ __device__ __forceinline__ void zero_b(FragS& f) {
     for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
 }
 
-// One K group (32 channels), tap-major: tap t's MFMAs, then slot t of the weight ring is refilled
-// with tap t of the NEXT K group (`wn`, may be null) -- the weight stream runs one K group (~4,700
-// MFMA cycles) ahead, also across jobs and stage barriers.  With MORE the activation operands are
-// refilled in place for the next K group (LDS slot address a1) after the last tap that reads
-// them: cell 0 after tap 4, cells 1-2 after tap 5, 3 and 6 after tap 7, the rest after tap 8.
+// One K group (32 channels), tap-major.  The weight ring holds three taps: tap t's operands sit in slot t % 3 and, once
+// its MFMAs are issued, the slot is refilled with tap t + 3 -- of this K group (`wc`) or, for the last three taps, with
+// taps 0-2 of the NEXT K group (`wn`; when nothing follows, any readable weights: the loads are unconditional) -- so the weight stream runs three taps ahead, also
+// across jobs and stage barriers.  With MORE the activation operands are refilled in place for the next K group (LDS
+// slot address a1) after the last tap that reads them: cell 0 after tap 4, cells 1-2 after tap 5, 3 and 6 after tap 7,
+// the rest after tap 8 (for a partial output-cell group the last reader can only be earlier).
 template <int OMASK, bool MORE>
 __device__ __forceinline__ void kgroup(f32x4 (&acc)[CELLS], Pieces (&x)[CELLS], FragS& f,
                                        const unsigned char* __restrict__ src, int a1,
-                                       const float* __restrict__ wn, int lane) {
-  tap_mfma<OMASK, 0>(acc, x, f.rb[0]); if (wn != nullptr) load_tap(f.rb[0], wn + 0 * TAP_DWORDS, lane);
-  tap_mfma<OMASK, 1>(acc, x, f.rb[1]); if (wn != nullptr) load_tap(f.rb[1], wn + 1 * TAP_DWORDS, lane);
-  tap_mfma<OMASK, 2>(acc, x, f.rb[2]); if (wn != nullptr) load_tap(f.rb[2], wn + 2 * TAP_DWORDS, lane);
-  tap_mfma<OMASK, 3>(acc, x, f.rb[3]); if (wn != nullptr) load_tap(f.rb[3], wn + 3 * TAP_DWORDS, lane);
-  tap_mfma<OMASK, 4>(acc, x, f.rb[4]); if (wn != nullptr) load_tap(f.rb[4], wn + 4 * TAP_DWORDS, lane);
+                                       const float* __restrict__ wc, const float* __restrict__ wn, int lane) {
+  tap_mfma<OMASK, 0>(acc, x, f.rb[0]); load_tap(f.rb[0], wc + 3 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 1>(acc, x, f.rb[1]); load_tap(f.rb[1], wc + 4 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 2>(acc, x, f.rb[2]); load_tap(f.rb[2], wc + 5 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 3>(acc, x, f.rb[0]); load_tap(f.rb[0], wc + 6 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 4>(acc, x, f.rb[1]); load_tap(f.rb[1], wc + 7 * TAP_DWORDS, lane);
   if constexpr (MORE) load_cell<OMASK, 0>(x, src, a1);
-  tap_mfma<OMASK, 5>(acc, x, f.rb[5]); if (wn != nullptr) load_tap(f.rb[5], wn + 5 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 5>(acc, x, f.rb[2]); load_tap(f.rb[2], wc + 8 * TAP_DWORDS, lane);
   if constexpr (MORE) { load_cell<OMASK, 1>(x, src, a1); load_cell<OMASK, 2>(x, src, a1); }
-  tap_mfma<OMASK, 6>(acc, x, f.rb[6]); if (wn != nullptr) load_tap(f.rb[6], wn + 6 * TAP_DWORDS, lane);
-  tap_mfma<OMASK, 7>(acc, x, f.rb[7]); if (wn != nullptr) load_tap(f.rb[7], wn + 7 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 6>(acc, x, f.rb[0]); load_tap(f.rb[0], wn + 0 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 7>(acc, x, f.rb[1]); load_tap(f.rb[1], wn + 1 * TAP_DWORDS, lane);
   if constexpr (MORE) { load_cell<OMASK, 3>(x, src, a1); load_cell<OMASK, 6>(x, src, a1); }
-  tap_mfma<OMASK, 8>(acc, x, f.rb[8]); if (wn != nullptr) load_tap(f.rb[8], wn + 8 * TAP_DWORDS, lane);
+  tap_mfma<OMASK, 8>(acc, x, f.rb[2]); load_tap(f.rb[2], wn + 2 * TAP_DWORDS, lane);
   if constexpr (MORE) { load_cell<OMASK, 4>(x, src, a1); load_cell<OMASK, 5>(x, src, a1); load_cell<OMASK, 7>(x, src, a1); load_cell<OMASK, 8>(x, src, a1); }
 }
 // All K groups of one job as straight-line code (KG = 1 or 2: layers are at most 64 channels wide;
 // a loop would carry the operand registers around its back edge through copies).  On entry the
-// ring holds the taps of the job's first K group; on exit those of the next job that reads
-// weights (`w_after`, may be null).
+// ring holds the first three taps of the job's first K group; on exit those of the next job that reads
+// weights (`w_after`; the stream's start when there is none).
 template <int OMASK, int KG>
 __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, const unsigned char* __restrict__ src,
                                           const float* __restrict__ w, const float* __restrict__ w_after, int lane) {
@@ -232,10 +241,10 @@ __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, const u
   Pieces x[CELLS];
   load_cells<OMASK>(x, src, pos, quad, 0);
   if constexpr (KG == 2) {
-    kgroup<OMASK, true>(acc, x, f, src, slot_addr(0, pos, 4 + quad), w + NET_KG_DWORDS, lane);
-    kgroup<OMASK, false>(acc, x, f, src, 0, w_after, lane);
+    kgroup<OMASK, true>(acc, x, f, src, slot_addr(0, pos, 4 + quad), w, w + NET_KG_DWORDS, lane);
+    kgroup<OMASK, false>(acc, x, f, src, 0, w + NET_KG_DWORDS, w_after, lane);
   } else {
-    kgroup<OMASK, false>(acc, x, f, src, 0, w_after, lane);
+    kgroup<OMASK, false>(acc, x, f, src, 0, w, w_after, lane);
   }
 }
 
@@ -331,13 +340,13 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
   if (job.dst < NET_BUFFERS) {
     unsigned char* dst = lds + job.dst * ACT_BYTES;
     if (job.res >= 0) {
-      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 1, true>(acc, dst, lds + job.res * ACT_BYTES, lane, job.nt);
+      epilogue_lds<OMASK, 1, true>(acc, dst, lds + job.res * ACT_BYTES, lane, job.nt);
     } else if (job.act == 1) {
       epilogue_lds<OMASK, 1, false>(acc, dst, nullptr, lane, job.nt);
     } else if (job.act == 2) {
       epilogue_lds<OMASK, 2, false>(acc, dst, nullptr, lane, job.nt);
     } else if (job.act == 3) {
-      if constexpr (OMASK == 0x1FF) epilogue_lds<OMASK, 3, false>(acc, dst, nullptr, lane, job.nt);
+      epilogue_lds<OMASK, 3, false>(acc, dst, nullptr, lane, job.nt);
     } else {
       epilogue_lds<OMASK, 0, false>(acc, dst, nullptr, lane, job.nt);
     }
@@ -379,6 +388,9 @@ __device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float
                                         const float* w_after, unsigned char* __restrict__ lds,
                                         const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
                                         float* logits, float* value, Stamp&& stamp) {
+  // per-lane LDS addresses are derived inside the job from an opaque copy of the lane id: hoisted out of the job loop
+  // they are spilled and reloaded in the middle of the K loop, behind a wait for the whole weight stream
+  asm volatile("" : "+v"(lane));
   f32x4 acc[CELLS];
 #pragma unroll
   for (int o = 0; o < CELLS; ++o) acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -405,15 +417,18 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
                                          int policy_channels, int n_valid, float* logits, float* value,
                                          unsigned long long* stamps = nullptr) {
   unsigned char* __restrict__ lds = reinterpret_cast<unsigned char*>(lds_f);
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));                     // per-lane addresses are derived here, not hoisted out of the caller's loop
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const NetJob* __restrict__ jobs = prog->jobs[wave];
-  const int n_jobs = prog->n_jobs[wave];
+  // (uniform by construction; said explicitly for callers that pass `prog` as a generic pointer)
+  const int n_jobs = __builtin_amdgcn_readfirstlane(prog->n_jobs[wave]);
+  const int first_w = __builtin_amdgcn_readfirstlane(prog->first_w_off[wave]);
 
   FragS f;
   zero_b(f);
-  if (prog->first_w_off[wave] >= 0) load_b(f, W + prog->first_w_off[wave], lane);
+  if (first_w >= 0) load_b(f, W + first_w, lane);
 
   unsigned long long tk[4] = {0, 0, 0, 0}, ts = 0;
   auto stamp = [&](int slot) {
@@ -448,13 +463,15 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
       for (int i = 0; i < 6; ++i) nw[i] = jw[(j + 1) * 6 + i];
     }
     if (job.og != OG_NONE) {
-      const float* w_after = (job.kgroups > 0 && job.next_w_off >= 0) ? W + job.next_w_off : nullptr;
+      const float* w_after = W + (job.next_w_off >= 0 ? job.next_w_off : 0);   // never null: straight-line K loops
       switch (job.og) {
         case 0: run_job<og_mask(0)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
         case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
         case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
         case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        default: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 4: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        case 5: run_job<og_mask(5)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        default: run_job<og_mask(6)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
       }
     }
     stamp(2);

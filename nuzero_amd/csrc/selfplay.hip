@@ -50,6 +50,9 @@ __device__ __forceinline__ void expanded_near_root(RootCache& rc, Arena t, int r
 
 constexpr int LDS_TAB = 960;     // entries of the (sqrt, bias) tables kept in LDS: enough for 100 simulations per move
 
+// The tree phase runs on the first four waves (16 games x 16 lanes); the network phase on all eight.
+constexpr int TREE_THREADS = POS * LANES_PER_GAME;
+static_assert(TREE_THREADS <= NET_THREADS, "the tree phase's lanes are a prefix of the workgroup");
 // Tree-phase state of one row (game slot); see `park` below.
 struct RowState {
   bool alive = false, pending = false;
@@ -64,7 +67,7 @@ struct RowState {
 };
 constexpr int PARK_ROW_WORDS = 23, PARK_LANE_WORDS = 13;
 __device__ __forceinline__ void park(const RowState& s, const RootCache& rc, int32_t (*row)[POS],
-                                     int32_t (*lane)[NET_THREADS], int slot, int sub, int tid) {
+                                     int32_t (*lane)[TREE_THREADS], int slot, int sub, int tid) {
   if (sub == 0) {
     row[0][slot] = (s.alive ? 1 : 0) | (s.pending ? 2 : 0);
     row[1][slot] = s.g; row[2][slot] = s.root; row[3][slot] = s.node_count; row[4][slot] = s.sims_left;
@@ -83,7 +86,7 @@ __device__ __forceinline__ void park(const RowState& s, const RootCache& rc, int
   lane[9][tid] = __double2loint(rc.pr); lane[10][tid] = __double2hiint(rc.pr);
   lane[11][tid] = (int32_t)rc.lk.x; lane[12][tid] = (int32_t)rc.lk.y;
 }
-__device__ __forceinline__ void unpark(RowState& s, RootCache& rc, int32_t (*row)[POS], int32_t (*lane)[NET_THREADS],
+__device__ __forceinline__ void unpark(RowState& s, RootCache& rc, int32_t (*row)[POS], int32_t (*lane)[TREE_THREADS],
                                        int slot, int sub, int tid) {
   const int f = row[0][slot];
   s.alive = (f & 1) != 0; s.pending = (f & 2) != 0;
@@ -128,6 +131,21 @@ __device__ __forceinline__ int opaque(int v) {
   return v;
 }
 
+// The network phase as a real call: its registers are allocated on their own, as in the stand-alone network kernel
+// (inlined into the persistent loop the allocator spills ~140 registers around the job loop).
+__device__ __forceinline__ void net_phase(const NetProgram* prog, const float* W, float* lds, const float* inp,
+                                                    float* out_logits, float* out_value) {
+  // arguments of a device function arrive in vector registers; these two are uniform
+  auto uniform = [](const void* q) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(q);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+  };
+  net_tile(static_cast<const NetProgram*>(uniform(prog)), static_cast<const float*>(uniform(W)), lds, inp, 1, POS,
+           out_logits, out_value);
+}
+
 template <bool STAMPS>
 __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   __shared__ __attribute__((aligned(16))) float lds[NET_LDS_FLOATS + POS * TTT_ACTIONS + POS];
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   // meanwhile -- one word per game for what the 16 lanes of a row share, one per lane for the rest -- and lives in
   // registers only between `unpark` and `park`, so nothing is spilled to scratch memory around net_tile.
   __shared__ int32_t park_row[PARK_ROW_WORDS][POS];
-  __shared__ int32_t park_lane[PARK_LANE_WORDS][NET_THREADS];
+  __shared__ int32_t park_lane[PARK_LANE_WORDS][TREE_THREADS];
   // sqrt(N) and log((N + base + 1) / base) + init of the parent count (Explorer.py:103-112), first LDS_TAB entries:
   // the root's children are scored from registers, with these here a descent's first level touches no memory at all
   __shared__ double2 tab[LDS_TAB];
@@ -150,14 +168,16 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     const TreeParams& p = kernel_args().p;
     for (int i = threadIdx.x; i < LDS_TAB && i < p.tab_len; i += NET_THREADS) tab[i] = make_double2(p.sqrt_tab[i], p.bias_tab[i]);
     const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
-    const int gslot = blockIdx.x * POS + slot;
-    RootCache rc0;
-    root_cache_load(rc0, arena_of(p, gslot < p.n_slots ? gslot : 0), 0, sub);
-    RowState st0;
-    st0.alive = gslot < p.n_slots && gslot < p.n_games;
-    st0.g = gslot;                                     // game being played in this slot
-    st0.sims_left = p.sims;
-    park(st0, rc0, park_row, park_lane, slot, sub, tid);
+    if (tid < TREE_THREADS) {
+      const int gslot = blockIdx.x * POS + slot;
+      RootCache rc0;
+      root_cache_load(rc0, arena_of(p, gslot < p.n_slots ? gslot : 0), 0, sub);
+      RowState st0;
+      st0.alive = gslot < p.n_slots && gslot < p.n_games;
+      st0.g = gslot;                                     // game being played in this slot
+      st0.sims_left = p.sims;
+      park(st0, rc0, park_row, park_lane, slot, sub, tid);
+    }
   }
   unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0;
   if constexpr (STAMPS) t_begin = t0 = __builtin_amdgcn_s_memtime();
@@ -183,6 +203,8 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
       if (tid == 0) s_max_sims = 0;
       __syncthreads();
     }
+    bool row_alive = false, row_pending = false;
+    if (tid < TREE_THREADS) {                            // waves 4-7 only work in the network phase
     RowState st;
     RootCache rc;
     unpark(st, rc, park_row, park_lane, slot, sub, tid);
@@ -326,8 +348,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
       if (sub == 0) atomicMax(&s_max_sims, cyc_sims);
     }
     park(st, rc, park_row, park_lane, slot, sub, tid);
-    const int any_alive = __syncthreads_or(alive ? 1 : 0);
-    const int any_pending = __syncthreads_or(pending ? 1 : 0);
+    row_alive = alive;
+    row_pending = pending;
+    }
+    const int any_alive = __syncthreads_or(row_alive ? 1 : 0);
+    const int any_pending = __syncthreads_or(row_pending ? 1 : 0);
     if constexpr (STAMPS) {
       const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       t_tree += t1 - t0;
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     // ------------------------------ net phase ----------------------------------
     {
       const SelfplayArgs& na = kernel_args();
-      net_tile(na.prog, na.W, lds, inp, 1, POS, out_logits, out_value);
+      net_phase(na.prog, na.W, lds, inp, out_logits, out_value);
     }
     // net_tile ends with a barrier: outputs are visible to every row
     if constexpr (STAMPS) {
@@ -373,7 +398,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     }
   }
 
-  if (gslot < p.n_slots && sub == 0) {
+  if (tid < TREE_THREADS && gslot < p.n_slots && sub == 0) {
     p.alive[gslot] = 0;
     p.pending[gslot] = -1;
     p.n_root_children[gslot] = 0;

@@ -404,7 +404,7 @@ __device__ inline double np_sum(const double* v, int n) {
 }
 // np.random.choice(p=...): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
 __device__ inline int np_choice(const double* prob, int n, double u) {
-  double cdf[TTT_ACTIONS];
+  double cdf[TTT_ACTIONS] = {};      // fully initialised for the same reason as finish_move_one's arrays
   double run = 0.0;
   for (int i = 0; i < n; ++i) {
     run = (i == 0) ? prob[0] : run + prob[i];
@@ -438,7 +438,9 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, Arena t, int r
     atomicOr(p.error_flag, 4);      // search did not complete
     return r;
   }
-  int counts[TTT_ACTIONS], actions[TTT_ACTIONS];
+  // (fully initialised: these arrays become vector registers, and the entries a partial fill leaves alone would
+  // otherwise be carried -- as live registers -- around the caller's loop, network phase included)
+  int counts[TTT_ACTIONS] = {}, actions[TTT_ACTIONS] = {};
   for (int j = 0; j < k; ++j) {
     const TNode c = t[base + j];
     counts[j] = c.visit;
@@ -474,7 +476,7 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, Arena t, int r
   } else if (mode == 1) {     // softmax_action (Explorer.py:187-199)
     int mx = counts[0];
     for (int j = 1; j < k; ++j) mx = counts[j] > mx ? counts[j] : mx;
-    double e[TTT_ACTIONS];
+    double e[TTT_ACTIONS] = {};
     for (int j = 0; j < k; ++j) e[j] = exp((double)(counts[j] - mx));
     const double s = np_sum(e, k);
     for (int j = 0; j < k; ++j) e[j] = e[j] / s;
