@@ -206,7 +206,8 @@ bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::
   for (const StageConv& sc : stage) {
     const PackedConv& pc = convs[sc.tensor];
     for (int nt = 0; nt < pc.ntiles; ++nt) {
-      const int pieces = !sc.split || pc.ntiles >= NET_WAVES_HOST ? 1 : 2 * pc.ntiles >= NET_WAVES_HOST ? 2 : 4;
+      if (!sc.split || pc.ntiles >= NET_WAVES_HOST) return false;   // whole-tile jobs (group 0) are not compiled in
+      const int pieces = 2 * pc.ntiles >= NET_WAVES_HOST ? 2 : 4;
       const int og_first = pieces == 1 ? 0 : pieces == 2 ? 5 : 1, og_last = pieces == 1 ? 0 : pieces == 2 ? 6 : 4;
       for (int og = og_first; og <= og_last; ++og) {
         NetJob j{};
@@ -517,7 +518,7 @@ nz_status nz_engine_set_weights(nz_engine* e, const nz_net_desc* net, const floa
   stage({{vh, cur, side, -1, vact, true}});
   stage({{vh + 1, side, cur, -1, vact, true}});
   stage({{vh + 2, cur, side, -1, vact, true}});
-  stage({{vh + 3, side, NET_DST_VALUE, -1, 0, false}});                     // mean over cells needs all nine
+  stage({{vh + 3, side, NET_DST_VALUE, -1, 0, true}});                      // per-cell outputs; net_tile takes the mean
   if (!ok) return fail(e, NZ_ERR_ARG, "network too deep for one fused launch (%d iterations)", recurrent_iterations);
   for (int w = 0; w < NET_WAVES_HOST; ++w) {     // prefetch chain: each job names the next weight stream
     int32_t next = -1;

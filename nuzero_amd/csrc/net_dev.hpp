@@ -68,7 +68,8 @@ constexpr int PIECE_BYTES = CELLS * POS * ROW * 2;          // one bf16 piece of
 constexpr int ACT_BYTES = 3 * PIECE_BYTES;
 constexpr int ACT_FLOATS = ACT_BYTES / 4;                   // LDS is declared as float[] by the kernels
 constexpr int INP_FLOATS = CELLS * POS * 4;
-constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
+constexpr int VAL_FLOATS = CELLS * POS;                      // the value head's last layer, per cell, before the mean
+constexpr int NET_LDS_FLOATS = NET_BUFFERS * ACT_FLOATS + INP_FLOATS + VAL_FLOATS;
 constexpr int TAP_DWORDS = 3 * 64 * 4;                      // one tap of one K group: [piece][lane][8 bf16]
 constexpr int W_RING = 3;                                   // taps in flight: the weight stream runs three taps ahead of the MFMAs
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
@@ -336,7 +337,7 @@ __device__ __forceinline__ void epilogue_lds(const f32x4 (&acc)[CELLS], unsigned
 }
 template <int OMASK>
 __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob& job, unsigned char* __restrict__ lds,
-                                         int lane, int policy_channels, int n_valid, float* logits, float* value) {
+                                         int lane, int policy_channels, int n_valid, float* logits, float* vcells) {
   if (job.dst < NET_BUFFERS) {
     unsigned char* dst = lds + job.dst * ACT_BYTES;
     if (job.res >= 0) {
@@ -367,17 +368,14 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
         }
       }
     }
-  } else {                                     // value: mean over (C=1,H,W), tanh (blocks.py:82-84)
-    if constexpr (OMASK == 0x1FF) {
-      int l2 = lane;                           // as for the policy: no address hoisted out of the job loop
-      asm volatile("" : "+v"(l2));
-      const int pos = l2 & 15, quad = l2 >> 4;
-      if (job.nt == 0 && quad == 0 && pos < n_valid) {
-        float s = 0.0f;
+  } else {                                     // value: channel 0 of every cell; net_tile takes the mean when all are in
+    int l2 = lane;                             // as for the policy: no address hoisted out of the job loop
+    asm volatile("" : "+v"(l2));
+    const int pos = l2 & 15, quad = l2 >> 4;
+    if (job.nt == 0 && quad == 0) {
 #pragma unroll
-        for (int o = 0; o < CELLS; ++o) s += acc[o][0];
-        value[pos] = tanh_fast(s / 9.0f);
-      }
+      for (int o = 0; o < CELLS; ++o)
+        if ((OMASK >> o) & 1) vcells[o * POS + pos] = acc[o][0];
     }
   }
 }
@@ -399,13 +397,13 @@ __device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float
   stamp(0);
   if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
   stamp(1);
-  epilogue<OMASK>(acc, job, lds, lane, policy_channels, n_valid, logits, value);
+  epilogue<OMASK>(acc, job, lds, lane, policy_channels, n_valid, logits, value);   // `value`: the per-cell staging area
   stamp(2);
 }
 
 // Run the compiled network on the 16 positions whose input planes are in `inp`
 // ([cell][pos][4 planes]); `lds_f` holds the activation buffers (NET_BUFFERS * ACT_FLOATS floats,
-// no NaN bit patterns: the callers zero it once).  Every thread of the 256-thread workgroup must
+// no NaN bit patterns: the callers zero it once), then `inp`'s INP_FLOATS, then VAL_FLOATS of staging.  Every thread of the 256-thread workgroup must
 // call it; it ends with a workgroup barrier.
 // Outputs: logits [pos][policy_channels][9] and value [pos] for pos < n_valid
 // (any address space).
@@ -417,6 +415,7 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
                                          int policy_channels, int n_valid, float* logits, float* value,
                                          unsigned long long* stamps = nullptr) {
   unsigned char* __restrict__ lds = reinterpret_cast<unsigned char*>(lds_f);
+  float* const vcells = lds_f + NET_BUFFERS * ACT_FLOATS + INP_FLOATS;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));                     // per-lane addresses are derived here, not hoisted out of the caller's loop
   const int lane = tid & 63;
@@ -431,6 +430,10 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   if (first_w >= 0) load_b(f, W + first_w, lane);
 
   unsigned long long tk[4] = {0, 0, 0, 0}, ts = 0;
+#ifdef NZ_STAGE_STAMPS
+  unsigned long long pk[3] = {0, 0, 0}, st_rec[24][3];
+  int n_st = 0;
+#endif
   auto stamp = [&](int slot) {
     if constexpr (STAMPS) {
       const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -465,22 +468,46 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
     if (job.og != OG_NONE) {
       const float* w_after = W + (job.next_w_off >= 0 ? job.next_w_off : 0);   // never null: straight-line K loops
       switch (job.og) {
-        case 0: run_job<og_mask(0)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 4: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        case 5: run_job<og_mask(5)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
-        default: run_job<og_mask(6)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, value, stamp); break;
+        // (group 0, all nine cells in one job, is never scheduled: layers are at most four tiles wide and eight waves
+        // want a unit each -- engine.hip add_stage)
+        case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        case 4: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        case 5: run_job<og_mask(5)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        default: run_job<og_mask(6)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
       }
     }
     stamp(2);
     if (job.stage_end) __syncthreads();
     stamp(3);
+#ifdef NZ_STAGE_STAMPS   // diagnostic build: per-stage ticks of waves 0 and 4 of workgroup 0 (K loops + planes, epilogue, barrier)
+    if constexpr (STAMPS) {
+      if (job.stage_end && blockIdx.x == 0 && (tid == 0 || tid == 256) && n_st < 24) {
+        st_rec[n_st][0] = tk[0] + tk[1] - pk[0]; st_rec[n_st][1] = tk[2] - pk[1]; st_rec[n_st][2] = tk[3] - pk[2];
+        ++n_st;
+        pk[0] = tk[0] + tk[1]; pk[1] = tk[2]; pk[2] = tk[3];
+      }
+    }
+#endif
   }
+  // value = tanh(mean over (C=1,H,W)) (blocks.py:82-84); the last stage's jobs left channel 0 of each cell in `vcells`
+  // (the program's last stage ends with a barrier).  Cells are added in index order, whichever wave produced them.
+  if (tid < POS && tid < n_valid) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int o = 0; o < CELLS; ++o) sum += vcells[o * POS + tid];
+    value[tid] = tanh_fast(sum / 9.0f);
+  }
+  __syncthreads();
   if constexpr (STAMPS) {
     if (tid == 0)
       for (int i = 0; i < 4; ++i) stamps[i] = tk[i];
+#ifdef NZ_STAGE_STAMPS
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256))
+      for (int i = 0; i < n_st; ++i)
+        printf("wave %d stage %d: k %llu epi %llu bar %llu\n", wave, i, st_rec[i][0], st_rec[i][1], st_rec[i][2]);
+#endif
   }
 }
 

@@ -150,7 +150,7 @@ template <bool STAMPS>
 __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   __shared__ __attribute__((aligned(16))) float lds[NET_LDS_FLOATS + POS * TTT_ACTIONS + POS];
   float* const inp = lds + NET_BUFFERS * ACT_FLOATS;
-  float* const out_logits = inp + INP_FLOATS;          // [16][9]
+  float* const out_logits = inp + INP_FLOATS + VAL_FLOATS;   // [16][9], after net_tile's own areas
   float* const out_value = out_logits + POS * TTT_ACTIONS;
 
   // K groups may reach past a narrow layer's channels (their weights are zero): no NaN bit patterns in LDS
