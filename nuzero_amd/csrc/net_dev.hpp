@@ -75,11 +75,13 @@ constexpr int W_RING = 3;                                   // taps in flight: t
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
 static_assert(NET_KG_DWORDS == 9 * TAP_DWORDS && NET_KG_CHANNELS == 32, "host packing (engine.hip) and kernel agree");
 
-// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} | two halves {0,1,2,3,5} {4,6,7,8}
-// ((input cell, tap) pairs: 49 | 13, 12, 12, 12 | 26, 23)
+// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} | a tile in two uneven parts {0,2,3,5,6,7,8}
+// {1,4}   ((input cell, tap) pairs: 49 | 13, 12, 12, 12 | 34, 15).  The two parts go to the two waves of a SIMD: the
+// older one wins the matrix pipe, so the big part's epilogue runs under the small part's MFMAs and only the small
+// part's two-cell epilogue is left when the stage's MFMAs end.
 __host__ __device__ constexpr int og_mask(int og) {
   return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 :
-         og == 5 ? 0x02F : og == 6 ? 0x1D0 : 0;
+         og == 5 ? 0x1ED : og == 6 ? 0x012 : 0;
 }
 
 // byte offset of the 16-byte slot holding channels 8 s .. 8 s + 7 of (cell, pos) inside one piece
