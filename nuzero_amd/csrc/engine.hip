@@ -199,7 +199,7 @@ struct StageConv {
   int tensor, src, dst, res, act;
   bool split;   // each output tile may be cut into output-cell groups (halves or quarters) to give every wave a unit
 };
-const int og_taps[7] = {49, 13, 12, 12, 12, 34, 15};   // (input cell, tap) pairs per output-cell group (net_dev.hpp og_mask)
+const int og_taps[7] = {49, 13, 12, 12, 12, 26, 23};   // (input cell, tap) pairs per output-cell group (net_dev.hpp og_mask)
 bool add_stage(NetProgram& pg, const std::vector<PackedConv>& convs, const std::vector<StageConv>& stage) {
   struct Unit { NetJob job; int cost; };
   std::vector<Unit> units;

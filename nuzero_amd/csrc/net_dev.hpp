@@ -75,13 +75,13 @@ constexpr int W_RING = 3;                                   // taps in flight: t
 static_assert(NET_WAVES == NET_WAVES_HOST, "job lists are per wave");
 static_assert(NET_KG_DWORDS == 9 * TAP_DWORDS && NET_KG_CHANNELS == 32, "host packing (engine.hip) and kernel agree");
 
-// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} | a tile in two uneven parts {0,2,3,5,6,7,8}
-// {1,4}   ((input cell, tap) pairs: 49 | 13, 12, 12, 12 | 34, 15).  The two parts go to the two waves of a SIMD: the
-// older one wins the matrix pipe, so the big part's epilogue runs under the small part's MFMAs and only the small
-// part's two-cell epilogue is left when the stage's MFMAs end.
+// output-cell groups: all nine | four quarters {4,0} {1,3} {5,7} {2,6,8} | two halves {0,1,2,3,5} {4,6,7,8}
+// ((input cell, tap) pairs: 49 | 13, 12, 12, 12 | 26, 23).  The halves of a tile go to the two waves of a SIMD: the older
+// wave wins the matrix pipe, so its epilogue runs under the other's MFMAs and one epilogue is left when those end.
+// (An uneven 7 + 2 split leaves a shorter epilogue but measured the same and spilled four registers in the large job.)
 __host__ __device__ constexpr int og_mask(int og) {
   return og == 0 ? 0x1FF : og == 1 ? 0x011 : og == 2 ? 0x00A : og == 3 ? 0x0A0 : og == 4 ? 0x144 :
-         og == 5 ? 0x1ED : og == 6 ? 0x012 : 0;
+         og == 5 ? 0x02F : og == 6 ? 0x1D0 : 0;
 }
 
 // byte offset of the 16-byte slot holding channels 8 s .. 8 s + 7 of (cell, pos) inside one piece
@@ -276,10 +276,13 @@ template <int OMASK>
 __device__ __forceinline__ void extra_planes(f32x4 (&acc)[CELLS], const float* __restrict__ wx,
                                              const float* __restrict__ inp, int lane) {
   float ax[CELLS], bx[9];
+  // (explicit address spaces: a FLAT load in flight makes every later wait in the job a full vmcnt(0) / lgkmcnt(0))
+  const __attribute__((address_space(1))) float* wxg = (const __attribute__((address_space(1))) float*)wx;
+  const __attribute__((address_space(3))) float* inl = (const __attribute__((address_space(3))) float*)inp;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) bx[t] = wx[t * 64 + lane];
+  for (int t = 0; t < 9; ++t) bx[t] = wxg[t * 64 + lane];
 #pragma unroll
-  for (int i = 0; i < CELLS; ++i) ax[i] = inp[(i * POS + (lane & 15)) * 4 + (lane >> 4)];
+  for (int i = 0; i < CELLS; ++i) ax[i] = inl[(i * POS + (lane & 15)) * 4 + (lane >> 4)];
   mfma_extra_tap<OMASK, 0>(acc, ax, bx); mfma_extra_tap<OMASK, 1>(acc, ax, bx); mfma_extra_tap<OMASK, 2>(acc, ax, bx);
   mfma_extra_tap<OMASK, 3>(acc, ax, bx); mfma_extra_tap<OMASK, 4>(acc, ax, bx); mfma_extra_tap<OMASK, 5>(acc, ax, bx);
   mfma_extra_tap<OMASK, 6>(acc, ax, bx); mfma_extra_tap<OMASK, 7>(acc, ax, bx); mfma_extra_tap<OMASK, 8>(acc, ax, bx);
@@ -451,7 +454,8 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   static_assert(sizeof(NetJob) == 24, "six dwords");
   int vzero;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));                  // a zero the compiler must keep in a vector register
-  const uint32_t* jw = reinterpret_cast<const uint32_t*>(jobs) + vzero;
+  const __attribute__((address_space(1))) uint32_t* jw =
+      (const __attribute__((address_space(1))) uint32_t*)reinterpret_cast<const uint32_t*>(jobs) + vzero;   // global, not FLAT
   uint32_t nw[6];
 #pragma unroll
   for (int i = 0; i < 6; ++i) nw[i] = jw[i];
@@ -463,6 +467,10 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
       for (int i = 0; i < 6; ++i) cw[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)nw[i]);
       __builtin_memcpy(&job, cw, sizeof(job));
     }
+    // Every vector load still in flight here was issued a whole epilogue ago (this job's first three taps): an explicit
+    // wait costs nothing and gives the K loop exact counts.  Left to itself the compiler, which cannot count loads across
+    // the loop's back edges, makes the first wait inside the job a vmcnt(0) -- behind the taps issued just before it.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
     if (j + 1 < n_jobs) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) nw[i] = jw[(j + 1) * 6 + i];

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   const SelfplayArgs& ea = kernel_args();
   const TreeParams& p = ea.p;
   unsigned long long* const stamps = ea.stamps;
-  const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
+  const int tid = opaque(threadIdx.x), slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);   // (not the prologue's copies)
   const int gslot = blockIdx.x * POS + slot;
   if constexpr (STAMPS) {
     if (tid == 0) {

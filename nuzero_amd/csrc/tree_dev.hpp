@@ -402,6 +402,9 @@ __device__ inline double np_sum(const double* v, int n) {
   for (int i = 8; i < n; ++i) r = r + v[i];
   return r;
 }
+// exp() behind a real call: inlined, its polynomial's constants are hoisted to the top of the persistent kernel and kept
+// (in the self-play kernel: in scratch memory, written and read back every cycle) for a function a game calls once a move
+__device__ __attribute__((noinline)) double exp_call(double x) { return exp(x); }
 // np.random.choice(p=...): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
 __device__ inline int np_choice(const double* prob, int n, double u) {
   double cdf[TTT_ACTIONS] = {};      // fully initialised for the same reason as finish_move_one's arrays
@@ -477,7 +480,7 @@ __device__ inline MoveResult finish_move_one(const TreeParams& p, Arena t, int r
     int mx = counts[0];
     for (int j = 1; j < k; ++j) mx = counts[j] > mx ? counts[j] : mx;
     double e[TTT_ACTIONS] = {};
-    for (int j = 0; j < k; ++j) e[j] = exp((double)(counts[j] - mx));
+    for (int j = 0; j < k; ++j) e[j] = exp_call((double)(counts[j] - mx));
     const double s = np_sum(e, k);
     for (int j = 0; j < k; ++j) e[j] = e[j] / s;
     const double s2 = np_sum(e, k);
