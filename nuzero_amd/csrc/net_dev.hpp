@@ -386,11 +386,11 @@ __device__ __forceinline__ void epilogue(const f32x4 (&acc)[CELLS], const NetJob
 }
 
 // one job: K loop, input-plane step, epilogue
-template <int OMASK, typename Stamp>
+template <int OMASK, typename Stamp, typename Fetch>
 __device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float* __restrict__ W,
                                         const float* w_after, unsigned char* __restrict__ lds,
                                         const float* __restrict__ inp, int lane, int policy_channels, int n_valid,
-                                        float* logits, float* value, Stamp&& stamp) {
+                                        float* logits, float* value, Stamp&& stamp, Fetch&& fetch_next) {
   // per-lane LDS addresses are derived inside the job from an opaque copy of the lane id: hoisted out of the job loop
   // they are spilled and reloaded in the middle of the K loop, behind a wait for the whole weight stream
   asm volatile("" : "+v"(lane));
@@ -402,6 +402,7 @@ __device__ __forceinline__ void run_job(const NetJob& job, FragS& f, const float
   stamp(0);
   if (job.extra) extra_planes<OMASK>(acc, W + job.wx_off, inp, lane);
   stamp(1);
+  fetch_next();          // the next job's descriptor: in flight under the epilogue, in no register during the K loop
   epilogue<OMASK>(acc, job, lds, lane, policy_channels, n_valid, logits, value);   // `value`: the per-cell staging area
   stamp(2);
 }
@@ -448,7 +449,7 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
   };
   if constexpr (STAMPS) ts = __builtin_amdgcn_s_memtime();
 
-  // The next job's descriptor is fetched while this job computes -- with VECTOR loads (every lane reads the same six
+  // The next job's descriptor is fetched while this job's epilogue runs -- with VECTOR loads (every lane reads the same six
   // words, v_readfirstlane makes them scalars again).  As a scalar load it would share lgkmcnt with the K loop's LDS
   // operand reads and return out of order with them; that variant computes wrong outputs.
   static_assert(sizeof(NetJob) == 24, "six dwords");
@@ -471,21 +472,24 @@ __device__ __forceinline__ void net_tile(const NetProgram* __restrict__ prog, co
     // wait costs nothing and gives the K loop exact counts.  Left to itself the compiler, which cannot count loads across
     // the loop's back edges, makes the first wait inside the job a vmcnt(0) -- behind the taps issued just before it.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
-    if (j + 1 < n_jobs) {
+    auto fetch_next = [&]() {
+      if (j + 1 < n_jobs) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) nw[i] = jw[(j + 1) * 6 + i];
-    }
+        for (int i = 0; i < 6; ++i) nw[i] = jw[(j + 1) * 6 + i];
+      }
+    };
+    if (job.og == OG_NONE) fetch_next();
     if (job.og != OG_NONE) {
       const float* w_after = W + (job.next_w_off >= 0 ? job.next_w_off : 0);   // never null: straight-line K loops
       switch (job.og) {
         // (group 0, all nine cells in one job, is never scheduled: layers are at most four tiles wide and eight waves
         // want a unit each -- engine.hip add_stage)
-        case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
-        case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
-        case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
-        case 4: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
-        case 5: run_job<og_mask(5)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
-        default: run_job<og_mask(6)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp); break;
+        case 1: run_job<og_mask(1)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
+        case 2: run_job<og_mask(2)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
+        case 3: run_job<og_mask(3)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
+        case 4: run_job<og_mask(4)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
+        case 5: run_job<og_mask(5)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
+        default: run_job<og_mask(6)>(job, f, W, w_after, lds, inp, lane, policy_channels, n_valid, logits, vcells, stamp, fetch_next); break;
       }
     }
     stamp(2);
