@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--nodes-per-sim", type=int, default=0,
                     help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game); "
                          "0 = the engine's board-scaled default")
+    ap.add_argument("--round-games", type=int, default=0,
+                    help="games per round (default: one per concurrent game); more: finished slots start the round's next "
+                         "game (nz_scs_search_play_round)")
     ap.add_argument("--streams", type=int, default=1,
                     help="split the concurrent games into this many independent sets, each with its own engine, network "
                          "buffers, host thread and HIP stream (native evaluator, library loop): their small kernels overlap")
@@ -113,7 +116,8 @@ def main():
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
     sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None,
                      device=local)
-    seeds = range(rank * args.games, (rank + 1) * args.games)       # game index = rank * games + g
+    n_round = max(args.round_games, args.games)
+    seeds = range(rank * n_round, (rank + 1) * n_round)             # game index = rank * games per round + g
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
     if world > 1:
@@ -150,7 +154,7 @@ def main():
         for k in ("simulations", "expansions", "waves"):
             r[k] = sum(x[k] for x in results)
     elif args.evaluator == "native" and args.loop == "library":
-        r = sp.play_native(net, seeds)
+        r = sp.play_round(net, seeds) if n_round > args.games else sp.play_native(net, seeds)
     else:
         r = sp.play(ev, seeds=seeds)
     if world > 1:                                  # the round's games to rank 0's replay buffer
@@ -159,7 +163,7 @@ def main():
     if world > 1:
         td.barrier()
     dt = time.perf_counter() - t0
-    totals = torch.tensor([dt, float(args.games), float(r["expansions"]), float(r["simulations"])], dtype=torch.float64,
+    totals = torch.tensor([dt, float(n_round), float(r["expansions"]), float(r["simulations"])], dtype=torch.float64,
                           device="cuda")
     if world > 1:
         tmax = totals.clone()
@@ -183,7 +187,8 @@ def main():
                       "waves": r.get("waves"), "n_gpus": world, "scaling": "weak", "streams": args.streams,
                       "games_per_s": n_games / dt, "expansions_per_s": n_exp / dt,
                       "simulations_per_s": n_sim / dt, "seconds": dt,
-                      "mean_game_length": float(r["lengths"].mean()),
+                      "games_per_round": int(n_games), "mean_game_length": float(r["lengths"].mean()),
+                      "game_length_p50_p90_max": [int(v) for v in np.percentile(r["lengths"], [50, 90, 100])],
                       "outcomes": {str(v): int((r["outcomes"] == v).sum()) for v in (-1, 0, 1)}, **out}))
     if world > 1:
         td.destroy_process_group()

@@ -396,6 +396,20 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
  * bounds a check on a large board / a heavy network without changing what is checked. */
 nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int32_t max_moves,
                                    void* stream);
+
+/* A round of n_round >= n_games games over the engine's n_games slots: a slot whose game has ended hands its records to
+ * the round's store and starts the round's next game, as a Gamer actor plays its games back to back
+ * (Training/Gamer.py:45-98) -- the round ends with its longest game instead of idling the slots of short ones.  Game i
+ * is seeded with seeds_host[i] (numpy RandomState(seed), the reference's draw order) whichever slot plays it, so a
+ * round's games do not depend on the number of slots.  n_round == n_games is nz_scs_search_play. */
+nz_status nz_scs_search_play_round(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int64_t n_round,
+                                   void* stream);
+/* nz_scs_search_export for the last round of more games than slots: every array has n_round rows;
+ * status2 [n_round][2] = (length, terminal value).  Device pointers, any may be null. */
+nz_status nz_scs_search_export_round(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
+                                     double* bias, double* root_value_sum, int32_t* child_action, int32_t* child_visit,
+                                     double* child_prior, double* child_value_sum, int32_t* status2,
+                                     int64_t* counters_host, void* stream);
 /* Diagnostic (library built with -DNZ_SCS_STAMPS, zeros otherwise): shader ticks summed over games and waves since
  * the last reset; out6: expansion, rules copy, scratch clone, descent, leaf mask + image, terminal simulations. */
 nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host);

@@ -123,6 +123,8 @@ SIGNATURES = {
     "nz_boardnet_fused": (c_int32, [c_void_p, c_int32, POINTER(c_int32)]),
     "nz_scs_search_play": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_play_moves": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "nz_scs_search_play_round": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nz_scs_search_export_round": (c_int32, [c_void_p] + [c_void_p] * 10 + [c_void_p, c_void_p]),
     "nz_scs_search_waves": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_scs_search_apply": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_last_actions": (c_int32, [c_void_p, c_void_p, c_void_p]),

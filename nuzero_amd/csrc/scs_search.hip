@@ -231,6 +231,66 @@ __global__ void search_reset_kernel(SearchParams p) {
   }
 }
 
+// ---- rounds of more games than slots (nz_scs_search_play_round) ----------------------------------------------------
+// A finished game's records leave its slot for the round's store (one row per game of the round), then the slot starts
+// the next game of the round: Gamer actors play their games back to back (Gamer.py:45-98), and a round ends no later
+// than its longest game instead of idling every slot whose game was short.
+struct RoundStore {
+  int32_t *action, *tree_size, *children, *child_action, *child_visit, *status;   // status [n][2]: length, terminal value
+  double *bias, *root_value_sum, *child_prior, *child_value_sum;
+};
+// one workgroup per slot; `to_record[g]` = row of the store that takes slot g's game, or -1
+__global__ void archive_kernel(SearchParams p, RoundStore st, const int32_t* __restrict__ to_record) {
+  const int g = blockIdx.x;
+  const int rec = to_record[g];
+  if (rec < 0) return;
+  const ScsState& real = p.real[g];
+  const int M = p.max_moves, MAXC = p.maxc;
+  const int len = real.length < M ? real.length : M;
+  const size_t src = (size_t)g * M, dst = (size_t)rec * M;
+  for (int m = threadIdx.x; m < M; m += blockDim.x) {
+    const bool played = m < len;
+    st.action[dst + m] = played ? p.rec_action[src + m] : -1;
+    st.tree_size[dst + m] = played ? p.rec_tree_size[src + m] : 0;
+    st.children[dst + m] = played ? p.rec_children[src + m] : 0;
+    st.bias[dst + m] = played ? p.rec_bias[src + m] : 0.0;
+    st.root_value_sum[dst + m] = played ? p.rec_root_value_sum[src + m] : 0.0;
+  }
+  for (int i = threadIdx.x; i < len * MAXC; i += blockDim.x) {
+    const int m = i / MAXC, j = i - m * MAXC;
+    if (j < p.rec_children[src + m]) {
+      st.child_action[dst * MAXC + i] = p.rec_child_action[src * MAXC + i];
+      st.child_visit[dst * MAXC + i] = p.rec_child_visit[src * MAXC + i];
+      st.child_prior[dst * MAXC + i] = p.rec_child_prior[src * MAXC + i];
+      st.child_value_sum[dst * MAXC + i] = p.rec_child_value_sum[src * MAXC + i];
+    }
+  }
+  if (threadIdx.x == 0) {
+    st.status[rec * 2] = real.length;
+    st.status[rec * 2 + 1] = real.terminal_value;
+  }
+}
+// search_reset_kernel for the slots with restart[g] != 0 (counters and flags are the round's: untouched)
+__global__ void restart_kernel(SearchParams p, const int32_t* __restrict__ restart) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= p.n_games || !restart[g]) return;
+  Scs(*p.rules, p.real[g]).reset();
+  p.half[g] = 0;
+  SNode& n = p.nodes[(size_t)g * p.cap];
+  n.prior = 0.0; n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = 0;
+  n.to_play = -1; n.prior_f64 = 0; n.terminal = 0; n.pad = 0;
+  p.node_count[g] = 1;
+  p.root[g] = 0;
+  p.sims_left[g] = 0;
+  p.pending[g] = -1;
+  p.path_len[g] = 0;
+  for (int m = 0; m < p.max_moves; ++m) {
+    p.rec_action[(size_t)g * p.max_moves + m] = -1;
+    p.rec_children[(size_t)g * p.max_moves + m] = 0;
+    p.rec_tree_size[(size_t)g * p.max_moves + m] = 0;
+  }
+}
+
 // children of each live game's root (the number of gamma draws of the next move)
 __global__ void root_children_kernel(SearchParams p, int32_t* out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -760,6 +820,10 @@ struct nz_scs_search {
   int32_t *leaf_game = nullptr, *nchild = nullptr, *status = nullptr;
   double *noise = nullptr, *uniforms = nullptr;
   int64_t waves = 0;
+  // nz_scs_search_play_round: the round's store and the slot bookkeeping of one move
+  RoundStore round{};
+  int64_t round_capacity = 0, round_games = 0;
+  int32_t *to_record = nullptr, *restart = nullptr;
   int32_t* counters_base = nullptr;          // 6 ints: two (leaf, active, cache hit) triples
   // inference cache (nz_scs_search_cache)
   int cache_bits = 0;
@@ -943,6 +1007,13 @@ void nz_scs_search_destroy(nz_scs_search* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* q : h->allocs) (void)hipFree(q);
+  {
+    const RoundStore& r = h->round;
+    void* store[] = {r.action, r.tree_size, r.children, r.child_action, r.child_visit, r.status, r.bias, r.root_value_sum,
+                     r.child_prior, r.child_value_sum};
+    for (void* q : store)
+      if (q) (void)hipFree(q);
+  }
   if (h->p.c_id) { (void)hipFree(h->p.c_id); (void)hipFree(h->p.c_probs); (void)hipFree(h->p.c_value); (void)hipFree(h->p.c_writer); }
   delete h;
 }
@@ -1050,9 +1121,44 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
   return nz_scs_search_play_moves(h, net, seeds_host, 0, stream);
 }
 
-nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int32_t max_moves,
-                                   void* stream) {
+}  // extern "C"
+
+namespace {
+// (re)allocate the round's store for `n` games
+nz_status round_store(nz_scs_search* h, int64_t n) {
+  if (n <= h->round_capacity) return NZ_OK;
+  RoundStore& r = h->round;
+  void* old[] = {r.action, r.tree_size, r.children, r.child_action, r.child_visit, r.status, r.bias, r.root_value_sum,
+                 r.child_prior, r.child_value_sum};
+  for (void* q : old)
+    if (q) (void)hipFree(q);
+  r = RoundStore{};
+  h->round_capacity = 0;
+  const size_t NM = (size_t)n * h->p.max_moves, NMC = NM * h->p.maxc;
+  const bool ok = hipMalloc((void**)&r.action, NM * 4) == hipSuccess && hipMalloc((void**)&r.tree_size, NM * 4) == hipSuccess &&
+                  hipMalloc((void**)&r.children, NM * 4) == hipSuccess && hipMalloc((void**)&r.bias, NM * 8) == hipSuccess &&
+                  hipMalloc((void**)&r.root_value_sum, NM * 8) == hipSuccess &&
+                  hipMalloc((void**)&r.child_action, NMC * 4) == hipSuccess && hipMalloc((void**)&r.child_visit, NMC * 4) == hipSuccess &&
+                  hipMalloc((void**)&r.child_prior, NMC * 8) == hipSuccess && hipMalloc((void**)&r.child_value_sum, NMC * 8) == hipSuccess &&
+                  hipMalloc((void**)&r.status, (size_t)n * 2 * 4) == hipSuccess;
+  if (!ok) return sfail(h, NZ_ERR_HIP, "device allocation failed (round store for %lld games)", (long long)n);
+  // unplayed moves' child rows are never written by archive_kernel: keep them defined
+  S_HIP(h, hipMemset(r.child_action, 0, NMC * 4)); S_HIP(h, hipMemset(r.child_visit, 0, NMC * 4));
+  S_HIP(h, hipMemset(r.child_prior, 0, NMC * 8)); S_HIP(h, hipMemset(r.child_value_sum, 0, NMC * 8));
+  h->round_capacity = n;
+  return NZ_OK;
+}
+
+// The library's move loop.  n_round == n_games: one game per slot (nz_scs_search_play_moves).  n_round > n_games: a round
+// of n_round games over the engine's slots -- a slot whose game has ended hands its records to the round's store and
+// starts the next game of the round (nz_scs_search_play_round); game i of the round is seeded with seeds_host[i]
+// wherever and whenever it runs, so the round's games do not depend on the number of slots.
+nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int64_t n_round, int32_t max_moves,
+                    void* stream) {
   if (!h || !net || (h->cfg.training && !seeds_host)) return sfail(h, NZ_ERR_ARG, "null argument");
+  const bool refill = n_round > h->n_games;
+  if (n_round < h->n_games) return sfail(h, NZ_ERR_ARG, "a round has at least one game per slot (%d)", h->n_games);
+  if (refill && max_moves > 0) return sfail(h, NZ_ERR_ARG, "max_moves applies to one game per slot only");
   S_HIP(h, hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int G = h->n_games;
@@ -1090,15 +1196,62 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
   nz_status st = nz_scs_search_reset(h, stream);
   if (st != NZ_OK) return st;
   h->waves = 0;
+  h->round_games = 0;
+  std::vector<int32_t> slot_game(G), to_record(G), restart(G);     // round bookkeeping: the game each slot is playing
+  int64_t next_game = G;
+  for (int g = 0; g < G; ++g) slot_game[g] = g;
+  if (refill) {
+    st = round_store(h, n_round);
+    if (st != NZ_OK) return st;
+    if (!h->to_record && !(dalloc(h, &h->to_record, (size_t)G) && dalloc(h, &h->restart, (size_t)G)))
+      return sfail(h, NZ_ERR_HIP, "device allocation failed");
+  }
   const dim3 grid1((G + 127) / 128), block1(128);
-  const int move_limit = max_moves > 0 && max_moves < MAX_MOVES ? max_moves : MAX_MOVES;
-  for (int move = 0; move < move_limit; ++move) {
+  const int64_t move_limit = refill ? (int64_t)MAX_MOVES * ((n_round + G - 1) / G + 1)
+                                    : (max_moves > 0 && max_moves < MAX_MOVES ? max_moves : MAX_MOVES);
+  for (int64_t move = 0; move < move_limit; ++move) {
     hipLaunchKernelGGL(search_status_kernel, grid1, block1, 0, s, h->p, h->status);
     if (h->cfg.training) hipLaunchKernelGGL(root_children_kernel, grid1, block1, 0, s, h->p, h->nchild);
     S_HIP(h, hipMemcpyAsync(status.data(), h->status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (h->cfg.training)
       S_HIP(h, hipMemcpyAsync(nchild.data(), h->nchild, nchild.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     S_HIP(h, hipStreamSynchronize(s));
+    if (refill) {
+      bool archive = false, restarted = false;
+      for (int g = 0; g < G; ++g) {
+        to_record[g] = -1;
+        restart[g] = 0;
+        if (!status[(size_t)g * 7 + 4] || slot_game[g] < 0) continue;
+        to_record[g] = slot_game[g];                 // the slot's game is over: its records go to the round's store
+        archive = true;
+        if (next_game < n_round) {                    // and the slot starts the round's next game
+          slot_game[g] = (int32_t)next_game;
+          if (h->cfg.training) {
+            nz_rng_destroy(rngs[g]);
+            rngs[g] = nz_rng_create(seeds_host[next_game]);
+          }
+          ++next_game;
+          restart[g] = 1;
+          restarted = true;
+        } else {
+          slot_game[g] = -1;
+        }
+      }
+      if (archive) {
+        S_HIP(h, hipMemcpyAsync(h->to_record, to_record.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(archive_kernel, dim3(G), dim3(64), 0, s, h->p, h->round, h->to_record);
+      }
+      if (restarted) {
+        S_HIP(h, hipMemcpyAsync(h->restart, restart.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(restart_kernel, grid1, block1, 0, s, h->p, h->restart);
+        hipLaunchKernelGGL(search_status_kernel, grid1, block1, 0, s, h->p, h->status);
+        if (h->cfg.training) hipLaunchKernelGGL(root_children_kernel, grid1, block1, 0, s, h->p, h->nchild);
+        S_HIP(h, hipMemcpyAsync(status.data(), h->status, status.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (h->cfg.training)
+          S_HIP(h, hipMemcpyAsync(nchild.data(), h->nchild, nchild.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      }
+      if (archive) S_HIP(h, hipStreamSynchronize(s));     // the bookkeeping vectors are reused next move
+    }
     bool any = false;
     for (int g = 0; g < G; ++g) any |= status[(size_t)g * 7 + 4] == 0;
     if (!any) break;
@@ -1159,6 +1312,54 @@ nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uin
   h->p.active_count = counters + 1;
   h->p.hit_count = counters + 2;
   h->p.clear_counters = nullptr;
+  if (refill) {
+    for (int g = 0; g < G; ++g)
+      if (slot_game[g] >= 0) return sfail(h, NZ_ERR_STATE, "internal: the round did not finish in %lld moves", (long long)move_limit);
+    h->round_games = n_round;
+  }
+  return NZ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+nz_status nz_scs_search_play_moves(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int32_t max_moves,
+                                   void* stream) {
+  return play_impl(h, net, seeds_host, h ? h->n_games : 0, max_moves, stream);
+}
+
+// A round of n_round >= n_games games over the engine's slots (see play_impl); read it with nz_scs_search_export_round.
+nz_status nz_scs_search_play_round(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int64_t n_round,
+                                   void* stream) {
+  return play_impl(h, net, seeds_host, n_round, 0, stream);
+}
+
+// nz_scs_search_export for the last nz_scs_search_play_round with more games than slots: arrays of n_round rows, and
+// status [n_round][2] = (length, terminal value) of every game.  (A round of exactly n_games games is read with
+// nz_scs_search_export / nz_scs_search_status.)
+nz_status nz_scs_search_export_round(nz_scs_search* h, int32_t* actions, int32_t* tree_size, int32_t* n_children,
+                                     double* bias, double* root_value_sum, int32_t* child_action, int32_t* child_visit,
+                                     double* child_prior, double* child_value_sum, int32_t* status2,
+                                     int64_t* counters_host, void* stream) {
+  if (!h) return NZ_ERR_ARG;
+  if (h->round_games <= 0) return sfail(h, NZ_ERR_STATE, "no finished round of more games than slots");
+  S_HIP(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const RoundStore& r = h->round;
+  const size_t NM = (size_t)h->round_games * h->p.max_moves;
+  const int MAXC = h->p.maxc;
+#define CP(dst, src, n)                                                                          \
+  if (dst) S_HIP(h, hipMemcpyAsync(dst, src, (n) * sizeof(*src), hipMemcpyDeviceToDevice, s))
+  CP(actions, r.action, NM); CP(tree_size, r.tree_size, NM); CP(n_children, r.children, NM);
+  CP(bias, r.bias, NM); CP(root_value_sum, r.root_value_sum, NM);
+  CP(child_action, r.child_action, NM * MAXC); CP(child_visit, r.child_visit, NM * MAXC);
+  CP(child_prior, r.child_prior, NM * MAXC); CP(child_value_sum, r.child_value_sum, NM * MAXC);
+  CP(status2, r.status, (size_t)h->round_games * 2);
+#undef CP
+  if (counters_host) {
+    S_HIP(h, hipMemcpyAsync(counters_host, h->p.counters, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    S_HIP(h, hipStreamSynchronize(s));
+  }
   return NZ_OK;
 }
 

@@ -167,9 +167,9 @@ class Gamer:
             if not game_args:
                 raise ValueError("SCS needs game_args = [path of the game config]")
             self.scs_config = ScsGameConfig(game_args[0])
-            # `concurrent_games` trees play the round's `num_games` games in ceil(num_games / concurrent_games) batches
-            # (the reference's ActorPool of num_actors Gamers over num_games_per_step games, AlphaZero.py:525-577; games
-            # are independent and seeded by their index, so the batching does not change any game)
+            # `concurrent_games` trees play the round's `num_games` games: a tree whose game has ended starts the round's
+            # next one (the reference's ActorPool of num_actors Gamers over num_games_per_step games, AlphaZero.py:525-577;
+            # games are independent and seeded by their index, so which tree plays a game does not change it)
             self.concurrent = min(int(concurrent_games or num_games), num_games)
             self.engine = ScsSelfPlay(self.scs_config, search_config, self.concurrent, training=True, device=device)
             if self.cache_choice != "disabled":
@@ -242,20 +242,19 @@ class Gamer:
             self.engine.cache_clear()                  # a new round: new caches (AlphaZero.py:525-537)
         on_device = hasattr(self.buffer, "save_scs_games")
         records, stats = [], []
-        C = self.concurrent
-        for start in range(0, self.num_games, C):
-            n = min(C, self.num_games - start)
-            seeds = [self.base_seed + start + i for i in range(n)] + [0] * (C - n)     # a short last batch is padded
-            r = self.engine.play_native(self._board_net, seeds)
-            stats += round_stats({k: r[k][:n] for k in ("lengths", "tree_size", "n_children", "bias")})
-            if on_device:
-                self.buffer.save_scs_games(self.engine, self.engine.export_device(), self.game_index, n_games=n)
-            if self.records:
-                batch = scs_game_records(self.engine, r)[:n]
-                records += batch
-                if self.buffer is not None and not on_device:
-                    for rec in batch:
-                        self.buffer.save_game(rec, self.game_index)
+        # one round over the engine's `concurrent` slots: a slot whose game has ended starts the round's next game
+        # (nz_scs_search_play_round), as the reference's actors play their games back to back (Gamer.py:45-98)
+        seeds = [self.base_seed + i for i in range(self.num_games)]
+        t = self.engine.play_round_device(self._board_net, seeds)
+        r = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in t.items()}
+        stats = round_stats({k: r[k] for k in ("lengths", "tree_size", "n_children", "bias")})
+        if on_device:
+            self.buffer.save_scs_games(self.engine, t, self.game_index)
+        if self.records:
+            records = scs_game_records(self.engine, r)
+            if self.buffer is not None and not on_device:
+                for rec in records:
+                    self.buffer.save_game(rec, self.game_index)
         self.base_seed += self.num_games
         return records, stats
 

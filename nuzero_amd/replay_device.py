@@ -225,8 +225,8 @@ class DeviceReplayBuffer:
         are regenerated on the device by replaying the recorded actions through the device rules, one append per move;
         the policy targets come from the root's (action, visit) lists (SCS_Game.py:1517-1521)."""
         from .scs import ScsBatch
-        cfg, G = selfplay.cfg, selfplay.n_games
         r = result_device
+        cfg, G = selfplay.cfg, int(r["lengths"].shape[0])     # rows of the round (>= selfplay.n_games after play_round)
         lengths = r["lengths"].cpu().numpy()
         n_keep = G if n_games is None else int(n_games)
         dst = np.full((G, int(lengths.max())), -1, np.int64)

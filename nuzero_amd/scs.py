@@ -300,6 +300,45 @@ class ScsSelfPlay:
         out["waves"] = int(waves.value)
         return out
 
+    def play_round(self, net, seeds):
+        """A round of len(seeds) >= n_games games over this engine's n_games slots (nz_scs_search_play_round): a slot
+        whose game has ended starts the round's next game, as a Gamer actor plays its games back to back
+        (Training/Gamer.py:45-98).  Game i is seeded with seeds[i] whichever slot plays it -- the same games as
+        play_native on an engine of len(seeds) slots.  Returns export()'s dictionary with len(seeds) rows."""
+        return {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in self.play_round_device(net, seeds).items()}
+
+    def play_round_device(self, net, seeds):
+        """play_round with the records left on the device (export_device()'s dictionary, len(seeds) rows)."""
+        seeds = np.ascontiguousarray(np.asarray(list(seeds), dtype=np.uint32))
+        n = int(seeds.shape[0])
+        waves = ctypes.c_int64(0)
+        if n == self.n_games:
+            self._check(lib.nz_scs_search_play_moves(self._h, net._h, c_void_p(seeds.ctypes.data), 0, self._stream()))
+            t = self.export_device()
+        else:
+            self._check(lib.nz_scs_search_play_round(self._h, net._h, c_void_p(seeds.ctypes.data), n, self._stream()))
+            M, C, dev = self.MAX_MOVES, self.MAX_CHILDREN, self.device
+            t = {"actions": torch.empty((n, M), dtype=torch.int32, device=dev),
+                 "tree_size": torch.empty((n, M), dtype=torch.int32, device=dev),
+                 "n_children": torch.empty((n, M), dtype=torch.int32, device=dev),
+                 "bias": torch.empty((n, M), dtype=torch.float64, device=dev),
+                 "root_value_sum": torch.empty((n, M), dtype=torch.float64, device=dev),
+                 "child_action": torch.empty((n, M, C), dtype=torch.int32, device=dev),
+                 "child_visit": torch.empty((n, M, C), dtype=torch.int32, device=dev),
+                 "child_prior": torch.empty((n, M, C), dtype=torch.float64, device=dev),
+                 "child_value_sum": torch.empty((n, M, C), dtype=torch.float64, device=dev)}
+            st = torch.empty((n, 2), dtype=torch.int32, device=dev)
+            counters = (ctypes.c_int64 * 2)()
+            self._check(lib.nz_scs_search_export_round(self._h, *[c_void_p(t[k].data_ptr()) for k in (
+                "actions", "tree_size", "n_children", "bias", "root_value_sum", "child_action", "child_visit",
+                "child_prior", "child_value_sum")], c_void_p(st.data_ptr()), counters, self._stream()))
+            t["lengths"], t["outcomes"] = st[:, 0].contiguous(), st[:, 1].contiguous()
+            t["simulations"], t["expansions"] = int(counters[0]), int(counters[1])
+        self.evaluations = t["expansions"]
+        self._check(lib.nz_scs_search_waves(self._h, byref(waves)))
+        t["waves"] = int(waves.value)
+        return t
+
     def cache(self, max_entries):
         """The reference's inference cache for play_native (KeylessCache(max_size), Utils/Caches/KeylessCache.py:24-160):
         a device hash table of the largest power of two <= max_entries, shared by the engine's games; 0 switches it
@@ -399,8 +438,8 @@ class ScsGameRecord:
 def scs_game_records(selfplay, result):
     """GameRecords of a finished ScsSelfPlay round.  The per-move state images are regenerated by
     replaying the recorded actions through the device rules (ScsBatch), one image per decision."""
-    cfg, G = selfplay.cfg, selfplay.n_games
     lengths = result["lengths"]
+    cfg, G = selfplay.cfg, int(lengths.shape[0])        # rows of the round (>= selfplay.n_games after play_round)
     batch = ScsBatch(cfg, G, device=selfplay.device.index or 0)
     L = int(lengths.max())
     states = np.zeros((G, L, cfg.channels, cfg.rows, cfg.cols), np.float32)

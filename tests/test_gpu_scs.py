@@ -313,6 +313,53 @@ def test_scs_inference_cache_is_results_neutral(entries):
     assert cache.get_update_threshold() == 0.8 and cache.update(cache) is None
 
 
+def test_scs_round_refills_finished_slots():
+    """nz_scs_search_play_round: 22 games over 6 slots (a slot whose game has ended starts the round's next game; the
+    games end at different moves, so slots restart at different times) are, game for game and record for record, the 22
+    games a 22-slot engine plays from the same seeds; so is a second round on the same handle, and a round of exactly
+    one game per slot."""
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    path = os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsGameConfig(path)
+    N, G = 22, 6
+    w = synthetic_weights(9, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 2), 2.0)
+    net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=2, max_batch=N)
+    net.set_weights(w)
+    search = {"Simulation": {"mcts_simulations": 20, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 4, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.01, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.25,
+                              "root_dist_alpha": 0.15, "root_dist_beta": 1}}
+    seeds = list(range(700, 700 + N))
+    wide = ScsSelfPlay(cfg, search, N)
+    ra = wide.play_native(net, seeds)
+    assert len(set(ra["lengths"].tolist())) > 2, "the slots must restart at different moves for this test to bite"
+    narrow = ScsSelfPlay(cfg, search, G)
+    for attempt in range(2):
+        rb = narrow.play_round(net, seeds)
+        assert rb["actions"].shape[0] == N
+        for k in ("lengths", "outcomes", "actions", "tree_size", "n_children"):
+            assert np.array_equal(ra[k], rb[k]), (k, attempt)
+        for g in range(N):
+            n = ra["lengths"][g]
+            assert np.array_equal(ra["root_value_sum"][g, :n], rb["root_value_sum"][g, :n])
+            assert np.array_equal(ra["bias"][g, :n], rb["bias"][g, :n])
+            for m in range(n):
+                c = ra["n_children"][g, m]
+                for k in ("child_action", "child_visit", "child_prior", "child_value_sum"):
+                    assert np.array_equal(ra[k][g, m, :c], rb[k][g, m, :c]), (k, g, m)
+        assert rb["simulations"] == ra["simulations"] and rb["expansions"] == ra["expansions"]
+        assert rb["waves"] < ra["waves"] * (N / G)          # fewer waves than N / G rounds of one game per slot
+    rc = narrow.play_round(net, seeds[:G])                  # exactly one game per slot: the plain move loop
+    assert np.array_equal(rc["actions"], ra["actions"][:G]) and np.array_equal(rc["lengths"], ra["lengths"][:G])
+    from nuzero_amd._lib import NzError
+    with pytest.raises(NzError):
+        narrow.play_round(net, seeds[:G - 1])
+    wide.close(); narrow.close(); net.close()
+
+
 def test_scs_round_larger_than_the_concurrent_trees():
     """Gamer(num_games=10, concurrent_games=4) on SCS: the round is played in batches of 4 trees (the reference's
     ActorPool: num_actors workers over num_games_per_step games); every game equals the one a 10-tree engine plays."""
