@@ -30,6 +30,13 @@ Extra keys (N = 1)
                     1024 concurrent games, one whole round in the library (nz_scs_search_play)
   gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
                     save_game for every game, statistics), games/s
+  rounds_in_flight_2  the same rounds with two engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
+                    next round's workgroups take the compute units the current round's tail leaves idle), games/s --
+                    the reference's asynchronous mode (Gamers that play_forever); NOT `value`, whose rounds run one
+                    after the other so that the kernel's duration in `roofline` and in rocprofv3's stats is that of an
+                    undisturbed launch
+  scs_config4_round4  scs_config4 with four games per concurrent tree in one round (nz_scs_search_play_round: a tree
+                    whose game has ended starts the round's next game)
   cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
                     Explorer/Gamer path) on this box's host cores, one process per core, on a bounded sample
 """
@@ -97,8 +104,9 @@ def git_commit():
         return None
 
 
-def scs_config4(device):
-    """BASELINE.json configs[3] (square-conv form, the pinned one): one whole self-play round, in-library move loop."""
+def scs_config4(device, games_per_tree=1):
+    """BASELINE.json configs[3] (square-conv form, the pinned one): one whole self-play round, in-library move loop.
+    games_per_tree > 1: the round has that many games per concurrent tree (nz_scs_search_play_round)."""
     import torch
     from nuzero_amd.boardnet import BoardNet
     from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
@@ -110,23 +118,56 @@ def scs_config4(device):
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.15, "root_dist_beta": 1}}      # Configs/Search/a1_search_config.yaml
     G = 1024
+    N = G * games_per_tree
     net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=8, max_batch=G, device=device)
     net.set_weights(synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 8)))
     sp = ScsSelfPlay(cfg, search, G, device=device)
     sp.play_native(net, range(G), max_moves=2)            # warm-up: first launches, allocations
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    r = sp.play_native(net, range(10 ** 6, 10 ** 6 + G))
+    r = sp.play_round(net, range(10 ** 6, 10 ** 6 + N))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out = {"value": G / dt, "unit": "games/s", "expansions_per_s": r["expansions"] / dt,
-           "simulations_per_s": r["simulations"] / dt, "seconds": dt, "waves": r["waves"],
+    out = {"value": N / dt, "unit": "games/s", "expansions_per_s": r["expansions"] / dt,
+           "simulations_per_s": r["simulations"] / dt, "seconds": dt, "waves": r["waves"], "games_per_round": N,
            "net_tflops_algorithmic": r["expansions"] * net.flops_per_position / dt / 1e12,
            "workload": "SCS mirrored 5x5 map (stack 2, 86 planes, 525 actions), ConvNet(32 filters, 8 layers, 3x3 square "
                        "convs), 200 sims/move, 1024 concurrent self-play games, a1 search config, 1 GPU"}
     sp.close()
     net.close()
     return out
+
+
+def rounds_in_flight(cfg, weights, games, n_round, device, iters, rounds=6, depth=2):
+    """`rounds` self-play rounds through a RoundPipeline of `depth` engines (see the module docstring)."""
+    import torch
+    from nuzero_amd.engine import SelfPlayEngine, RoundPipeline
+
+    def make():
+        e = SelfPlayEngine(cfg, n_round, training=True, device=device, n_slots=games)
+        e.set_weights(weights, recurrent_iterations=iters)
+        return e
+
+    pipe = RoundPipeline(make, depth=depth)
+    seed = lambda i: (7 * 10 ** 6 + i) * n_round
+    for i in range(depth):                                  # warm-up: one round per engine
+        pipe.submit(seed(i), next_base_seed=seed(i + depth))
+    while pipe.pending:
+        pipe.collect()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    expansions = 0
+    for i in range(depth, depth + rounds):
+        if len(pipe.pending) == depth:
+            expansions += pipe.collect()[1].counters()["expansions"]
+        pipe.submit(seed(i), next_base_seed=seed(i + depth))
+    while pipe.pending:
+        expansions += pipe.collect()[1].counters()["expansions"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pipe.close()
+    return {"value": rounds * n_round / dt, "unit": "games/s", "expansions_per_s": expansions / dt, "rounds": rounds,
+            "engines": depth, "games_per_round": n_round, "concurrent_games_per_engine": games}
 
 
 def gamer_surface(cfg, weights, games, n_round, device, rounds=2):
@@ -372,7 +413,10 @@ def main():
         # ---- the reference-shaped surface and one SCS configuration, driver-timed
         out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
         out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
+        out["rounds_in_flight_2"] = rounds_in_flight(cfg, weights, args.games, n_round, local_rank, args.iters)
+        out["rounds_in_flight_2"]["vs_value"] = out["rounds_in_flight_2"]["value"] / out["value"]
         out["scs_config4"] = scs_config4(local_rank)
+        out["scs_config4_round4"] = scs_config4(local_rank, games_per_tree=4)
 
     if rank == 0:
         if cpu is not None:

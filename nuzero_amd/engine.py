@@ -319,3 +319,50 @@ class SelfPlayEngine:
         check(lib.nz_engine_profile_read(self._h, ms, n, byref(pos)), self._h)
         names = ("search", "network", "move_misc")
         return {k: {"ms": ms[i], "launches": n[i]} for i, k in enumerate(names)}
+
+
+class RoundPipeline:
+    """Self-play rounds of several engines in flight at once (the reference's asynchronous mode: Gamers that
+    `play_forever`, Training/Gamer.py:99-101, while the trainer consumes finished games).
+
+    A round ends with workgroups that have run out of games while others still play; with `depth` engines, each on its
+    own HIP stream and host thread, the next round's workgroups take the compute units the current round's tail leaves
+    idle.  Rounds are submitted and handed back in order; round i runs on engine i % depth, so its games are exactly
+    those SelfPlayEngine.play(base_seed) would play (every game has its own random stream)."""
+
+    def __init__(self, make_engine, depth=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.engines = [make_engine() for _ in range(depth)]
+        self.device = self.engines[0].device
+        with torch.cuda.device(self.device):
+            self.streams = [torch.cuda.Stream() for _ in self.engines]
+        self.pool = ThreadPoolExecutor(max_workers=depth)
+        self.pending = []                 # (round index, engine, future), oldest first
+        self.submitted = 0
+
+    def _run(self, k, base_seed, next_base_seed):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.streams[k]):
+            self.engines[k].play(base_seed=base_seed, next_base_seed=next_base_seed)
+            self.streams[k].synchronize()
+
+    def submit(self, base_seed, next_base_seed=None):
+        """Start the next round on the engine whose turn it is (it must have been collected: at most `depth` rounds
+        are in flight).  `next_base_seed`: the seed of the round this SAME engine will play next."""
+        k = self.submitted % len(self.engines)
+        assert all(e is not self.engines[k] for _, e, _ in self.pending), "collect() the engine's last round first"
+        self.pending.append((self.submitted, self.engines[k], self.pool.submit(self._run, k, base_seed, next_base_seed)))
+        self.submitted += 1
+
+    def collect(self):
+        """Wait for the oldest round in flight; returns (round index, its engine) -- read the engine's results before the
+        next submit() that lands on it."""
+        i, eng, fut = self.pending.pop(0)
+        fut.result()
+        return i, eng
+
+    def close(self):
+        while self.pending:
+            self.collect()
+        self.pool.shutdown()
+        for e in self.engines:
+            e.close()

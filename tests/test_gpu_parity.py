@@ -645,3 +645,47 @@ def test_next_round_randomness_drawn_ahead_changes_nothing(search_kat, net_kat):
     eng.play(base_seed=base)                                     # prepared data for base + 5 is ignored
     _compare_with_reference_games(eng.export(trace=True), games)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_round_pipeline_plays_the_same_rounds():
+    """RoundPipeline (two engines, two streams, rounds in flight together): every round's games are the ones a single
+    engine plays from the same base seed -- outcomes, lengths, visit records and counters."""
+    from nuzero_amd.engine import SelfPlayEngine, RoundPipeline
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    w = synthetic_recurrent_net_weights(3, 2, 1, 64, 2, True)
+    cfg = legacy_ttt_search_config(25)
+    N, SLOTS, ROUNDS = 96, 32, 5
+
+    def make():
+        e = SelfPlayEngine(cfg, N, training=True, device=0, n_slots=SLOTS)
+        e.set_weights(w, recurrent_iterations=2)
+        return e
+
+    def snapshot(e):
+        import torch
+        r = e.export()
+        return {k: v.cpu().numpy().copy() for k, v in r.items() if torch.is_tensor(v)}, dict(e.counters())
+
+    single = make()
+    want = []
+    for i in range(ROUNDS):
+        single.play(base_seed=1000 * i)
+        want.append(snapshot(single))
+    single.close()
+    pipe = RoundPipeline(make, depth=2)
+    got = {}
+    for i in range(ROUNDS):
+        if len(pipe.pending) == 2:
+            j, e = pipe.collect()
+            got[j] = snapshot(e)
+        pipe.submit(1000 * i, next_base_seed=1000 * (i + 2))
+    while pipe.pending:
+        j, e = pipe.collect()
+        got[j] = snapshot(e)
+    pipe.close()
+    for i in range(ROUNDS):
+        assert got[i][1] == want[i][1], i
+        for k in want[i][0]:
+            assert np.array_equal(got[i][0][k], want[i][0][k]), (i, k)
