@@ -30,7 +30,7 @@ Extra keys (N = 1)
                     1024 concurrent games, one whole round in the library (nz_scs_search_play)
   gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
                     save_game for every game, statistics), games/s
-  rounds_in_flight_2  the same rounds with two engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
+  rounds_in_flight_N  (only with --rounds-in-flight N) the same rounds with N engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
                     next round's workgroups take the compute units the current round's tail leaves idle), games/s --
                     the reference's asynchronous mode (Gamers that play_forever); NOT `value`, whose rounds run one
                     after the other so that the kernel's duration in `roofline` and in rocprofv3's stats is that of an
@@ -101,7 +101,7 @@ def git_commit():
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
                                        text=True).strip()
     except Exception:
-        return None
+        return os.environ.get("NZ_COMMIT")      # a snapshot without .git (the GPU box): the caller may say
 
 
 def scs_config4(device, games_per_tree=1):
@@ -216,6 +216,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel measurements after the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--rounds-in-flight", type=int, default=0,
+                    help="also measure the rounds with this many engines in flight (key rounds_in_flight_N); not part of "
+                         "the default run: overlapped launches would spoil the kernel's average duration in a "
+                         "rocprofv3 trace of the same command")
     args = ap.parse_args()
     n_round = args.round if args.round > 0 else 4 * args.games
 
@@ -413,8 +417,10 @@ def main():
         # ---- the reference-shaped surface and one SCS configuration, driver-timed
         out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
         out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
-        out["rounds_in_flight_2"] = rounds_in_flight(cfg, weights, args.games, n_round, local_rank, args.iters)
-        out["rounds_in_flight_2"]["vs_value"] = out["rounds_in_flight_2"]["value"] / out["value"]
+        if args.rounds_in_flight > 1:
+            key = "rounds_in_flight_%d" % args.rounds_in_flight
+            out[key] = rounds_in_flight(cfg, weights, args.games, n_round, local_rank, args.iters, depth=args.rounds_in_flight)
+            out[key]["vs_value"] = out[key]["value"] / out["value"]
         out["scs_config4"] = scs_config4(local_rank)
         out["scs_config4_round4"] = scs_config4(local_rank, games_per_tree=4)
 

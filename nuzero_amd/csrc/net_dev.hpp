@@ -105,6 +105,31 @@ constexpr bool input_used() {
          pair_used<OMASK, I, 6>() || pair_used<OMASK, I, 7>() || pair_used<OMASK, I, 8>();
 }
 
+// first / last tap (0..8) that reads input cell I for this output-cell group
+template <int OMASK, int I>
+constexpr int first_use() {
+  return pair_used<OMASK, I, 0>() ? 0 : pair_used<OMASK, I, 1>() ? 1 : pair_used<OMASK, I, 2>() ? 2 :
+         pair_used<OMASK, I, 3>() ? 3 : pair_used<OMASK, I, 4>() ? 4 : pair_used<OMASK, I, 5>() ? 5 :
+         pair_used<OMASK, I, 6>() ? 6 : pair_used<OMASK, I, 7>() ? 7 : 8;
+}
+template <int OMASK, int I>
+constexpr int last_use() {
+  return pair_used<OMASK, I, 8>() ? 8 : pair_used<OMASK, I, 7>() ? 7 : pair_used<OMASK, I, 6>() ? 6 :
+         pair_used<OMASK, I, 5>() ? 5 : pair_used<OMASK, I, 4>() ? 4 : pair_used<OMASK, I, 3>() ? 3 :
+         pair_used<OMASK, I, 2>() ? 2 : pair_used<OMASK, I, 1>() ? 1 : 0;
+}
+// When cell I's operands of the SECOND K group are read, on a timeline of 18 steps (step s < 9: after tap s of the first
+// K group; step 9 + t: before tap t of the second): not before the first group is done with the registers, and not
+// earlier than REFILL_AHEAD taps before the second group needs them -- operands that sit in registers for a whole K
+// group cost the large jobs their last free registers (a four-register spill around the K loop otherwise).
+constexpr int REFILL_AHEAD = 3;
+template <int OMASK, int I>
+constexpr int refill_step() {
+  constexpr int earliest = last_use<OMASK, I>();                       // after that tap of group one
+  constexpr int wanted = 9 + first_use<OMASK, I>() - REFILL_AHEAD;      // before that tap of group two
+  return wanted > earliest ? wanted : earliest;
+}
+
 struct Pieces {           // the three bf16 pieces of 8 channels (one lane's share of a 32-channel K group)
   u32x4 p[3];
 };
@@ -209,29 +234,57 @@ __device__ __forceinline__ void zero_b(FragS& f) {
     for (int piece = 0; piece < 3; ++piece) f.rb[t].p[piece] = u32x4{0u, 0u, 0u, 0u};
 }
 
+// the second K group's operands of every cell whose refill_step is STEP (slot address a1)
+template <int OMASK, int STEP>
+__device__ __forceinline__ void refill(Pieces (&x)[CELLS], const unsigned char* __restrict__ src, int a1) {
+  if constexpr (refill_step<OMASK, 0>() == STEP) load_cell<OMASK, 0>(x, src, a1);
+  if constexpr (refill_step<OMASK, 1>() == STEP) load_cell<OMASK, 1>(x, src, a1);
+  if constexpr (refill_step<OMASK, 2>() == STEP) load_cell<OMASK, 2>(x, src, a1);
+  if constexpr (refill_step<OMASK, 3>() == STEP) load_cell<OMASK, 3>(x, src, a1);
+  if constexpr (refill_step<OMASK, 4>() == STEP) load_cell<OMASK, 4>(x, src, a1);
+  if constexpr (refill_step<OMASK, 5>() == STEP) load_cell<OMASK, 5>(x, src, a1);
+  if constexpr (refill_step<OMASK, 6>() == STEP) load_cell<OMASK, 6>(x, src, a1);
+  if constexpr (refill_step<OMASK, 7>() == STEP) load_cell<OMASK, 7>(x, src, a1);
+  if constexpr (refill_step<OMASK, 8>() == STEP) load_cell<OMASK, 8>(x, src, a1);
+}
 // One K group (32 channels), tap-major.  The weight ring holds three taps: tap t's operands sit in slot t % 3 and, once
 // its MFMAs are issued, the slot is refilled with tap t + 3 -- of this K group (`wc`) or, for the last three taps, with
-// taps 0-2 of the NEXT K group (`wn`; when nothing follows, any readable weights: the loads are unconditional) -- so the weight stream runs three taps ahead, also
-// across jobs and stage barriers.  With MORE the activation operands are refilled in place for the next K group (LDS
-// slot address a1) after the last tap that reads them: cell 0 after tap 4, cells 1-2 after tap 5, 3 and 6 after tap 7,
-// the rest after tap 8 (for a partial output-cell group the last reader can only be earlier).
-template <int OMASK, bool MORE>
+// taps 0-2 of the NEXT K group (`wn`; when nothing follows, any readable weights: the loads are unconditional) -- so the
+// weight stream runs three taps ahead, also across jobs and stage barriers.  PART 1 / 2: the first / second K group of a
+// two-group job -- the activation operands of the second group are read in place (LDS slot address a1) at their
+// refill_step, some after a tap of the first group, the others before a tap of the second; PART 0: a one-group job.
+template <int OMASK, int PART>
 __device__ __forceinline__ void kgroup(f32x4 (&acc)[CELLS], Pieces (&x)[CELLS], FragS& f,
                                        const unsigned char* __restrict__ src, int a1,
                                        const float* __restrict__ wc, const float* __restrict__ wn, int lane) {
+  constexpr bool A = PART == 1, B = PART == 2;
+  if constexpr (B) refill<OMASK, 9>(x, src, a1);
   tap_mfma<OMASK, 0>(acc, x, f.rb[0]); load_tap(f.rb[0], wc + 3 * TAP_DWORDS, lane);
+  if constexpr (A) refill<OMASK, 0>(x, src, a1);
+  if constexpr (B) refill<OMASK, 10>(x, src, a1);
   tap_mfma<OMASK, 1>(acc, x, f.rb[1]); load_tap(f.rb[1], wc + 4 * TAP_DWORDS, lane);
+  if constexpr (A) refill<OMASK, 1>(x, src, a1);
+  if constexpr (B) refill<OMASK, 11>(x, src, a1);
   tap_mfma<OMASK, 2>(acc, x, f.rb[2]); load_tap(f.rb[2], wc + 5 * TAP_DWORDS, lane);
+  if constexpr (A) refill<OMASK, 2>(x, src, a1);
+  if constexpr (B) refill<OMASK, 12>(x, src, a1);
   tap_mfma<OMASK, 3>(acc, x, f.rb[0]); load_tap(f.rb[0], wc + 6 * TAP_DWORDS, lane);
+  if constexpr (A) refill<OMASK, 3>(x, src, a1);
+  if constexpr (B) refill<OMASK, 13>(x, src, a1);
   tap_mfma<OMASK, 4>(acc, x, f.rb[1]); load_tap(f.rb[1], wc + 7 * TAP_DWORDS, lane);
-  if constexpr (MORE) load_cell<OMASK, 0>(x, src, a1);
+  if constexpr (A) refill<OMASK, 4>(x, src, a1);
+  if constexpr (B) refill<OMASK, 14>(x, src, a1);
   tap_mfma<OMASK, 5>(acc, x, f.rb[2]); load_tap(f.rb[2], wc + 8 * TAP_DWORDS, lane);
-  if constexpr (MORE) { load_cell<OMASK, 1>(x, src, a1); load_cell<OMASK, 2>(x, src, a1); }
+  if constexpr (A) refill<OMASK, 5>(x, src, a1);
+  if constexpr (B) refill<OMASK, 15>(x, src, a1);
   tap_mfma<OMASK, 6>(acc, x, f.rb[0]); load_tap(f.rb[0], wn + 0 * TAP_DWORDS, lane);
+  if constexpr (A) refill<OMASK, 6>(x, src, a1);
+  if constexpr (B) refill<OMASK, 16>(x, src, a1);
   tap_mfma<OMASK, 7>(acc, x, f.rb[1]); load_tap(f.rb[1], wn + 1 * TAP_DWORDS, lane);
-  if constexpr (MORE) { load_cell<OMASK, 3>(x, src, a1); load_cell<OMASK, 6>(x, src, a1); }
+  if constexpr (A) refill<OMASK, 7>(x, src, a1);
+  if constexpr (B) refill<OMASK, 17>(x, src, a1);
   tap_mfma<OMASK, 8>(acc, x, f.rb[2]); load_tap(f.rb[2], wn + 2 * TAP_DWORDS, lane);
-  if constexpr (MORE) { load_cell<OMASK, 4>(x, src, a1); load_cell<OMASK, 5>(x, src, a1); load_cell<OMASK, 7>(x, src, a1); load_cell<OMASK, 8>(x, src, a1); }
+  if constexpr (A) refill<OMASK, 8>(x, src, a1);
 }
 // All K groups of one job as straight-line code (KG = 1 or 2: layers are at most 64 channels wide;
 // a loop would carry the operand registers around its back edge through copies).  On entry the
@@ -244,10 +297,11 @@ __device__ __forceinline__ void job_kloop(f32x4 (&acc)[CELLS], FragS& f, const u
   Pieces x[CELLS];
   load_cells<OMASK>(x, src, pos, quad, 0);
   if constexpr (KG == 2) {
-    kgroup<OMASK, true>(acc, x, f, src, slot_addr(0, pos, 4 + quad), w, w + NET_KG_DWORDS, lane);
-    kgroup<OMASK, false>(acc, x, f, src, 0, w + NET_KG_DWORDS, w_after, lane);
+    const int a1 = slot_addr(0, pos, 4 + quad);
+    kgroup<OMASK, 1>(acc, x, f, src, a1, w, w + NET_KG_DWORDS, lane);
+    kgroup<OMASK, 2>(acc, x, f, src, a1, w + NET_KG_DWORDS, w_after, lane);
   } else {
-    kgroup<OMASK, false>(acc, x, f, src, 0, w, w_after, lane);
+    kgroup<OMASK, 0>(acc, x, f, src, 0, w, w_after, lane);
   }
 }
 

@@ -2,8 +2,10 @@
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 C=${NZ_COMMIT:-unknown}
+export NZ_COMMIT=$C
 timeout -k 10 500 python3 $R/bench.py > $O/bench_stdout.log 2>$O/bench_stderr.log || { tail -20 $O/bench_stderr.log; exit 1; }
 tail -c 400 $O/bench_stdout.log
+timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --rounds-in-flight 2 --steps 2 > $O/bench_rounds_in_flight.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_rocprof.log 2>&1 || exit 1
 cp $(ls /tmp/p_bench/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_f.log 2>&1 || exit 1
