@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--nodes-per-sim", type=int, default=0,
                     help="tree arena per game = 1 + sims * this many nodes (32 B each; never freed within a game); "
                          "0 = the engine's board-scaled default")
+    ap.add_argument("--cache", type=int, default=0,
+                    help="entries of the device inference cache (the reference's cache_choice keyless / cache_max); 0: off")
     ap.add_argument("--round-games", type=int, default=0,
                     help="games per round (default: one per concurrent game); more: finished slots start the round's next "
                          "game (nz_scs_search_play_round)")
@@ -117,6 +119,8 @@ def main():
     sp = ScsSelfPlay(cfg, search, args.games, nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None,
                      device=local)
     n_round = max(args.round_games, args.games)
+    if args.cache > 0:
+        sp.cache(args.cache)
     seeds = range(rank * n_round, (rank + 1) * n_round)             # game index = rank * games per round + g
     ev(torch.zeros((1, cfg.channels, cfg.rows, cfg.cols), device="cuda"))     # solver search outside the timed region
     torch.cuda.synchronize()
@@ -176,6 +180,8 @@ def main():
         return
     out = {}
     native = args.evaluator == "native"
+    if args.cache > 0:
+        out["cache"] = sp.cache_stats()
     if os.environ.get("NZ_LIB_PATH") and args.streams == 1:      # a diagnostic build may carry the wave kernel's phase stamps
         out["wave_kernel_phase_ticks"] = sp.phase_ticks()
     print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, %s convs), %s evaluator, "
