@@ -754,6 +754,285 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
 #endif
 }
 
+// ---- the one-launch network on the BF16 matrix cores (fused16_net_kernel) -------------------------------------------
+// fused_net_kernel with the arithmetic of the Tic-Tac-Toe network (net_dev.hpp): every float32 is the exact sum of
+// three bf16 pieces, a product is the six piece products of weight >= 2^-16 on v_mfma_f32_16x16x32_bf16 with float32
+// accumulation (96 matrix-pipe cycles per 32 channels where eight v_mfma_f32_16x16x4_f32 take 256).  Activations live
+// in LDS as pieces, [piece][row][channel] bf16, split ONCE by the layer that makes them; a row's 16-byte chunks (eight
+// channels) are stored at chunk ^ ((row >> 2) & 3), so that the sixteen rows of a tile -- 64-byte rows for 32 channels --
+// spread over all banks without padding.  The logits and the value plane stay float32 rows for the softmax.
+struct Fused16Op {
+  const uint32_t* w;                       // [col tile][tap][32-channel group][piece][lane][4 dwords = 8 bf16]
+  int32_t off0, cs0, ps0, kg0;             // source 0: float offset, floats per row and per piece, piece stride, K groups
+  int32_t off1, cs1, ps1, kg1;             // source 1 (off1 = -1: none)
+  int32_t offd, csd, psd;                  // destination (psd = 0: float32 rows [row][csd])
+  int32_t offr, csr, psr;                  // residual (offr = -1: none)
+  int32_t ntiles, act;
+  int32_t w_lds, w_chunks;                 // 1: weights staged in LDS; 16-byte chunks of one column tile
+  int32_t w_slot, w_after_barrier;
+  int32_t pad;
+};
+struct Fused16Program {
+  int32_t n_ops, hw, h, wd, planes, hex;
+  int32_t zrow_index, lds_floats;           // every pieces buffer has a row of zeros at this index (never written)
+  int32_t clear_from, pad2;                 // LDS floats [clear_from, lds_floats) start as zeros: the activation buffers
+  int32_t wbuf_off[2];
+  int32_t in_off, in_cs, in_ps, pol_off, pol_cs, val_off, val_cs, pad;
+  int32_t zero_at_op, n_zero, zero_off[6], zero_len;   // rows of zeros to (re)make before that layer: buffers that take over a weight buffer's space
+  Fused16Op ops[FUSED_MAX_OPS];
+};
+constexpr int FUSED16_WREGS = 4;           // 16-byte chunks of the next layer's weights a thread carries (64 KB per layer)
+typedef const __attribute__((address_space(1))) u32x4* gptr4u;
+
+__device__ __forceinline__ void fetch_weights16(const Fused16Op& op, u32x4 (&wreg)[FUSED16_WREGS], int tid) {
+  const int total = op.ntiles * op.w_chunks;
+#pragma unroll
+  for (int j = 0; j < FUSED16_WREGS; ++j) {
+    const int i = tid + j * FUSED_THREADS;
+    if (i < total) wreg[j] = *((gptr4u)op.w + i);
+  }
+}
+__device__ __forceinline__ void store_weights16(const Fused16Op& op, float* wbuf, const u32x4 (&wreg)[FUSED16_WREGS], int tid) {
+  const int total = op.ntiles * op.w_chunks;
+#pragma unroll
+  for (int j = 0; j < FUSED16_WREGS; ++j) {
+    const int i = tid + j * FUSED_THREADS;
+    if (i < total) *reinterpret_cast<u32x4*>(wbuf + (size_t)i * 4) = wreg[j];
+  }
+}
+// one K step (32 channels of one tap): the six piece products, small terms first (net_dev.hpp pair_mfma)
+__device__ __forceinline__ void step16(f32x4& acc, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
+  acc = wide_mfma(a[1], b[1], acc);
+  acc = wide_mfma(a[2], b[0], acc);
+  acc = wide_mfma(a[0], b[2], acc);
+  acc = wide_mfma(a[1], b[0], acc);
+  acc = wide_mfma(a[0], b[1], acc);
+  acc = wide_mfma(a[0], b[0], acc);
+}
+// One (row tile, column tile) job as straight-line code: NTAPS x KGT steps.  `srow[tap]`: this lane's operand row of the
+// tap -- an off-board tap reads the buffer's row of zeros (row index = the workgroup's row count, never written).
+template <int NTAPS, int KGT, bool WLDS>
+__device__ __forceinline__ void conv16_job(f32x4& acc, const float* __restrict__ lds, const int (&srow)[NTAPS], int off0,
+                                           int cs0, int ps0, int kq, const float* __restrict__ wl,
+                                           const uint32_t* __restrict__ wg) {
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+    const int rbase = off0 + srow[tap] * cs0, sw = (srow[tap] >> 2) & 3;
+#pragma unroll
+    for (int kg = 0; kg < KGT; ++kg) {
+      const int a0 = rbase + (((kg * 4 + kq) ^ sw) << 2);
+      u32x4 a[3], b[3];
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) {
+        a[piece] = *reinterpret_cast<const u32x4*>(lds + a0 + piece * ps0);
+        if constexpr (WLDS) b[piece] = *reinterpret_cast<const u32x4*>(wl + ((tap * KGT + kg) * 3 + piece) * 256);
+        else b[piece] = *((gptr4u)(wg + ((tap * KGT + kg) * 3 + piece) * 256));
+      }
+      step16(acc, a, b);
+    }
+  }
+}
+// exact three-way split of one value; piece i as the bf16 bit pattern
+__device__ __forceinline__ void split3_bits(float v, uint16_t (&h)[3]) {
+  float r = v;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xFFFF0000u;
+    h[i] = (uint16_t)(bits >> 16);
+    r = r - __builtin_bit_cast(float, bits);
+  }
+}
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
+
+template <bool HEX>
+__global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused16Program* __restrict__ prog,
+                                                                    const float* __restrict__ in_rows, int in_channels,
+                                                                    const int32_t* __restrict__ n_dev, int n_host,
+                                                                    float* __restrict__ logits, float* __restrict__ probs,
+                                                                    float* __restrict__ value) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_pos = n_dev ? *n_dev : n_host;
+  const int P = (n_pos + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int p0 = blockIdx.x * P;
+  if (p0 >= n_pos) return;                                  // uniform per workgroup
+  const int np = min(P, n_pos - p0);
+  const int hw = prog->hw, H = prog->h, Wd = prog->wd, n_ops = prog->n_ops;
+  const int rows = np * hw, row_tiles = (rows + 15) >> 4;
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int kq = lane >> 4;
+#ifdef NZ_FUSED_STAMPS
+  unsigned long long tk_in = 0, tk_job[32], tk_bar[32], tk_k[32], tk_fin = 0, ts = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < 32; ++i) tk_k[i] = 0;
+#endif
+
+  // K groups reach past a narrow layer's channels and row tiles past the last row (zero weights, discarded rows): what
+  // they read must be numbers, so everything starts as zeros
+  for (int i = prog->clear_from + tid * 4; i < prog->lds_floats; i += FUSED_THREADS * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 3 * prog->in_cs; i += FUSED_THREADS)     // the input's row of zeros
+    lds[prog->in_off + (i / prog->in_cs) * prog->in_ps + prog->zrow_index * prog->in_cs + i % prog->in_cs] = 0.f;
+  __syncthreads();
+  {   // this workgroup's input rows, split into pieces (global row of (position n, cell c): ((n >> 4) * hw + c) * 16 + (n & 15))
+    const int cs = prog->in_cs, ps = prog->in_ps;
+    const int chunks = in_channels >> 3;                    // eight channels = one 16-byte chunk of a piece
+    for (int i = tid; i < rows * chunks; i += FUSED_THREADS) {
+      const int r = i / chunks, c8 = i - r * chunks;
+      const int pl = r / hw, cell = r - pl * hw, n = p0 + pl;
+      const size_t grow = ((size_t)(n >> 4) * hw + cell) * 16 + (n & 15);
+      const float* src = in_rows + grow * in_channels + c8 * 8;
+      u32x4 q0, q1, q2;
+      wide_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), q0, q1, q2);
+      float* d = lds + prog->in_off + r * cs + ((c8 ^ ((r >> 2) & 3)) << 2);
+      *reinterpret_cast<u32x4*>(d) = q0;
+      *reinterpret_cast<u32x4*>(d + ps) = q1;
+      *reinterpret_cast<u32x4*>(d + 2 * ps) = q2;
+    }
+  }
+  if (n_ops > 0 && prog->ops[0].w_lds) {
+    u32x4 wreg[FUSED16_WREGS];
+    fetch_weights16(prog->ops[0], wreg, tid);
+    store_weights16(prog->ops[0], lds + prog->wbuf_off[prog->ops[0].w_slot], wreg, tid);
+  }
+  __syncthreads();
+  FSTAMP(tk_in);
+
+  int rt_cached = -1, srow[ntaps];
+  const int zrow_index = prog->zrow_index;              // every buffer's row of zeros
+  for (int o = 0; o < n_ops; ++o) {
+    const Fused16Op op = prog->ops[o];
+    if (o == prog->zero_at_op) {                            // (the previous layer's barrier is behind us; the first reader is two layers on)
+      for (int i = tid; i < prog->n_zero * prog->zero_len; i += FUSED_THREADS)
+        lds[prog->zero_off[i / prog->zero_len] + i % prog->zero_len] = 0.f;
+    }
+    const bool next_lds = o + 1 < n_ops && prog->ops[o + 1].w_lds;
+    u32x4 wreg[FUSED16_WREGS];
+    if (next_lds) fetch_weights16(prog->ops[o + 1], wreg, tid);
+    const int kgt = op.kg0 + op.kg1;
+    const int n_jobs = row_tiles * op.ntiles;
+    const float* wbuf = lds + prog->wbuf_off[op.w_slot];
+    for (int job = wave; job < n_jobs; job += FUSED_WAVES) {
+      const int rt = job / op.ntiles, ct = job - rt * op.ntiles;
+      if (rt != rt_cached) {
+        rt_cached = rt;
+        const int row = rt * 16 + (lane & 15);
+        const bool row_ok = row < rows;
+        const int pl = row / hw, cell = row - pl * hw;
+        const int cy = cell / Wd, cx = cell - cy * Wd;
+#pragma unroll
+        for (int tap = 0; tap < ntaps; ++tap) {
+          const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+          const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+          const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+          srow[tap] = on ? row + dy * Wd + dx : zrow_index;
+        }
+      }
+#ifdef NZ_FUSED_STAMPS
+      const unsigned long long j0 = __builtin_amdgcn_s_memtime();
+#endif
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* wl = wbuf + (size_t)ct * op.w_chunks * 4 + lane * 4;            // LDS copy of the column tile
+      const uint32_t* wg = op.w + (size_t)ct * op.w_chunks * 4 + lane * 4;         // packed stream in L2
+      if (op.w_lds && kgt == 1) conv16_job<ntaps, 1, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      else if (op.w_lds && kgt == 2) conv16_job<ntaps, 2, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      else if (kgt == 1) conv16_job<ntaps, 1, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      else if (kgt == 2) conv16_job<ntaps, 2, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      else if (kgt == 3) conv16_job<ntaps, 3, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      else conv16_job<ntaps, 4, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+#ifdef NZ_FUSED_STAMPS
+      asm volatile("" :: "v"(acc));
+      if (o < 32) tk_k[o] += __builtin_amdgcn_s_memtime() - j0;
+#endif
+      const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int orow = rt * 16 + r4 + r;
+        if (orow < rows) {
+          float v = acc[r];
+          if (op.offr >= 0) {                               // the residual's pieces add up to the float32 it was split from
+            const uint16_t* rp = reinterpret_cast<const uint16_t*>(lds + op.offr + orow * op.csr +
+                                                                   (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
+            v += (bf16_bits_to_float(rp[0]) + bf16_bits_to_float(rp[2 * op.psr])) + bf16_bits_to_float(rp[4 * op.psr]);
+          }
+          v = activate(v, op.act);
+          if (op.psd == 0) {
+            lds[op.offd + orow * op.csd + col] = v;
+          } else {
+            uint16_t h3[3];
+            split3_bits(v, h3);
+            uint16_t* dp = reinterpret_cast<uint16_t*>(lds + op.offd + orow * op.csd +
+                                                       (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
+            dp[0] = h3[0];
+            dp[2 * op.psd] = h3[1];
+            dp[4 * op.psd] = h3[2];
+          }
+        }
+      }
+    }
+#ifdef NZ_FUSED_STAMPS
+    if (o < 32) FSTAMP(tk_job[o]);
+#endif
+    if (next_lds && !prog->ops[o + 1].w_after_barrier)
+      store_weights16(prog->ops[o + 1], lds + prog->wbuf_off[prog->ops[o + 1].w_slot], wreg, tid);
+    __syncthreads();
+    if (next_lds && prog->ops[o + 1].w_after_barrier) {
+      store_weights16(prog->ops[o + 1], lds + prog->wbuf_off[prog->ops[o + 1].w_slot], wreg, tid);
+      __syncthreads();
+    }
+#ifdef NZ_FUSED_STAMPS
+    if (o < 32) FSTAMP(tk_bar[o]);
+#endif
+  }
+
+  // softmax over ALL logits and value = tanh(mean): exactly fused_net_kernel's tail (the two outputs are float32 rows)
+  float* pol = lds + prog->pol_off;
+  const int pp = prog->pol_cs;
+  const float* val = lds + prog->val_off;
+  const int vp = prog->val_cs;
+  const int A = prog->planes * hw;
+  const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
+  for (int pl = wave; pl < np; pl += FUSED_WAVES) {
+    const size_t n = (size_t)(p0 + pl);
+    float* prow = pol + pl * hw * pp;
+    float mx = -INFINITY;
+    for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+      const float v = prow[cell * pp + plane];
+      if (logits) logits[n * A + i] = v;
+      mx = fmaxf(mx, v);
+      cell += dcell; plane += dplane;
+      if (cell >= hw) { cell -= hw; ++plane; }
+    }
+    for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w));
+    if (probs) {
+      float sum = 0.f;
+      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+        const float e = expf(prow[cell * pp + plane] - mx);
+        prow[cell * pp + plane] = e;
+        sum += e;
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
+      }
+      for (int w = 32; w; w >>= 1) sum += __shfl_xor(sum, w);
+      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+        probs[n * A + i] = prow[cell * pp + plane] / sum;
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
+      }
+    }
+    float sv = 0.f;
+    for (int c = lane; c < hw; c += 64) sv += val[(pl * hw + c) * vp];
+    for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w);
+    if (lane == 0) value[n] = tanhf(sv / (float)hw);
+  }
+#ifdef NZ_FUSED_STAMPS
+  FSTAMP(tk_fin);
+  if (blockIdx.x == 0 && (tid == 0 || tid == FUSED_THREADS - 64)) {
+    printf("fused16 wg0 wave %d np %d rows %d: input %llu finalize %llu\n", wave, np, rows, tk_in, tk_fin);
+    for (int o = 0; o < n_ops && o < 32; ++o) printf("  wave %d op %d kg %d ntiles %d wlds %d slot %d: jobs %llu (k loop %llu) barrier+stage %llu\n", wave, o, prog->ops[o].kg0, prog->ops[o].ntiles, prog->ops[o].w_lds, prog->ops[o].w_slot, tk_job[o], tk_k[o], tk_bar[o]);
+  }
+#endif
+}
+
 struct ConvOp {
   int src0, src1, res, dst;     // buffer ids (-1: none)
   int weight;                   // index into packed weights
@@ -763,6 +1042,8 @@ struct ConvOp {
 struct PackedConv {
   float* dev = nullptr;
   uint32_t* dev_split = nullptr;            // wide layers only (conv_wide_kernel)
+  uint32_t* dev16 = nullptr;                // fused16_net_kernel's stream [col tile][tap][32-ch group][piece][lane][4]
+  int kg0_32 = 0, kg1_32 = 0;
   int c0p = 0, c1p = 0, coutp = 0, cout = 0, cin = 0;
 };
 
@@ -786,6 +1067,9 @@ struct nz_boardnet {
   bool use_fused = true;
   int fused_grid = 0;
   size_t fused_lds_bytes = 0;
+  Fused16Program* fused16_dev = nullptr;    // the same on the BF16 matrix cores (ConvNet), preferred when built
+  int fused16_grid = 0;
+  size_t fused16_lds_bytes = 0;
   std::string error;
 };
 
@@ -854,6 +1138,44 @@ bool pack(nz_boardnet* h, const float* w0, const float* w1, int cout, int c0, in
           }
   if (hipMalloc((void**)&pc.dev, host.size() * sizeof(float)) != hipSuccess) return false;
   if (hipMemcpy(pc.dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return false;
+  if (pc.coutp <= 64) {     // narrow layer: the three-piece bf16 stream of the one-launch BF16 network
+    pc.kg0_32 = (c0p + 31) / 32; pc.kg1_32 = (c1p + 31) / 32;
+    const int kg32 = pc.kg0_32 + pc.kg1_32;
+    std::vector<uint32_t> sp((size_t)ntiles * ntaps * kg32 * 3 * 64 * 4, 0u);
+    auto pieces16 = [](float a, uint16_t p3[3]) {                     // a = p3[0] + p3[1] + p3[2], bf16 each (truncating)
+      float r = a;
+      for (int i = 0; i < 3; ++i) {
+        uint32_t bits;
+        memcpy(&bits, &r, 4);
+        bits &= 0xFFFF0000u;
+        p3[i] = (uint16_t)(bits >> 16);
+        float t;
+        memcpy(&t, &bits, 4);
+        r = r - t;
+      }
+    };
+    auto cin16 = [&](int kg, int within) {                            // channel `within` of 32-channel group kg -> tensor index
+      if (kg < pc.kg0_32) { const int ch = kg * 32 + within; return ch < c0 ? ch : -1; }
+      const int ch = (kg - pc.kg0_32) * 32 + within;
+      return ch < c1 ? c0 + ch : -1;
+    };
+    for (int nt = 0; nt < ntiles; ++nt)
+      for (int tap = 0; tap < ntaps; ++tap)
+        for (int kg = 0; kg < kg32; ++kg)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+              const int co = nt * 16 + (lane & 15);
+              const int ci0 = cin16(kg, (lane >> 4) * 8 + 2 * j), ci1 = cin16(kg, (lane >> 4) * 8 + 2 * j + 1);
+              uint16_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+              if (co < cout && ci0 >= 0) pieces16(weight(co, ci0, tap), lo);
+              if (co < cout && ci1 >= 0) pieces16(weight(co, ci1, tap), hi);
+              for (int piece = 0; piece < 3; ++piece)
+                sp[(((((size_t)nt * ntaps + tap) * kg32 + kg) * 3 + piece) * 64 + lane) * 4 + j] =
+                    (uint32_t)lo[piece] | ((uint32_t)hi[piece] << 16);
+            }
+    if (hipMalloc((void**)&pc.dev16, sp.size() * sizeof(uint32_t)) != hipSuccess) return false;
+    if (hipMemcpy(pc.dev16, sp.data(), sp.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return false;
+  }
   if (pc.coutp % 128 == 0 && c0p % 32 == 0 && c1p % 32 == 0) {      // wide layer: the split form for conv_wide_kernel
     const int kqt = (c0p + c1p) / 32, cts = pc.coutp / 128;
     std::vector<uint32_t> sp((size_t)cts * (ntaps + 1) * kqt * 3 * 8 * 64 * 4, 0u);
@@ -1068,6 +1390,130 @@ void build_fused(nz_boardnet* h, int trunk_out) {
   h->fused_grid = grid;
   h->fused_lds_bytes = bytes;
 }
+// The one-launch network on the BF16 matrix cores, for ConvNets (a chain: two activation buffers).  LDS, in floats:
+// [zeros][input pieces -- after the first layer: weight buffer 1][weight buffer 0][activations A][activations B]; the
+// heads read their weights straight from L2 and keep their buffers (logits, value plane, two hidden buffers) in weight
+// buffer 0, which the trunk no longer needs by then.
+void build_fused16(nz_boardnet* h) {
+  static const int force = getenv("NZ_BOARDNET_FUSED16") ? atoi(getenv("NZ_BOARDNET_FUSED16")) : -1;   // tuning experiments
+  const nz_net_desc& nd = h->net;
+  if (force == 0 || nd.arch != NZ_ARCH_CONVNET || (int)h->ops.size() > FUSED_MAX_OPS || h->inp % 8 != 0) return;
+  const int n_ops = (int)h->ops.size(), n_trunk = n_ops - 6;     // first layer + num_blocks layers, then 2 + 4 head layers
+  if (n_trunk < 1) return;
+  for (const PackedConv& pc : h->convs)
+    if (!pc.dev16) return;
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || n_cu <= 0) return;
+  const int grid = h->max_batch < n_cu ? h->max_batch : n_cu;
+  const int p_max = (h->max_batch + grid - 1) / grid;
+  const int rows = p_max * h->hw;                               // rows past the last one are never read or written
+  const int ntaps = nd.hex ? 7 : 9;
+  auto cs_of = [](int channels) { return (channels + 31) / 32 * 16; };           // floats per row and piece
+  auto pieces_floats = [&](int channels) { return (size_t)3 * (rows + 1) * cs_of(channels); };   // + the row of zeros
+  const size_t budget = 160 * 1024 / sizeof(float);
+  Fused16Program pg;
+  memset(&pg, 0, sizeof(pg));
+  size_t off = 0;
+  pg.zrow_index = rows;
+  const int W = nd.width;
+  // trunk weights: every staged layer has the same shape
+  size_t wslot = 0;
+  for (int i = 1; i < n_trunk; ++i) {
+    const PackedConv& pc = h->convs[i];
+    wslot = std::max(wslot, (size_t)(pc.coutp / 16) * ntaps * (pc.kg0_32 + pc.kg1_32) * 3 * 64 * 4);
+  }
+  if (wslot > (size_t)FUSED16_WREGS * FUSED_THREADS * 4) return;
+  const size_t in_floats = pieces_floats(h->inp);
+  const size_t region_i = std::max(in_floats, wslot);
+  const int off_i = (int)off; off += region_i;
+  const int off_w0 = (int)off;
+  const std::vector<int> pcn = head_channels(W, nd.policy_channels, 2);
+  const std::vector<int> vcn = head_channels(W, 1, 4);
+  const int hidden = std::max(std::max(pcn[1], vcn[1]), std::max(vcn[2], vcn[3]));
+  // (float32 rows take whole 16-channel output tiles: the padded channels of the last tile are stored too)
+  const int pol_cs = pad16(nd.policy_channels) + FUSED_PAD, val_cs = pad16(1) + FUSED_PAD;
+  const size_t pol_floats = ((size_t)rows * pol_cs + 3) / 4 * 4;
+  const size_t val_floats = ((size_t)rows * val_cs + 3) / 4 * 4;
+  const size_t heads = pol_floats + val_floats + 2 * pieces_floats(hidden);
+  const size_t region_w0 = std::max(wslot, heads);
+  off += region_w0;
+  const int off_a = (int)off; off += pieces_floats(W);
+  const int off_b = (int)off; off += pieces_floats(W);
+  off = (off + 3) / 4 * 4;
+  if (off > budget) return;
+  pg.lds_floats = (int32_t)off;
+  // (the staged layers leave finite weights in the first `wslot` floats of weight buffer 0 before the heads move in)
+  pg.clear_from = off_w0 + (n_trunk > 1 ? (int)wslot : 0);
+  pg.n_ops = n_ops;
+  pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
+  pg.planes = nd.policy_channels; pg.hex = nd.hex ? 1 : 0;
+  pg.in_off = off_i; pg.in_cs = cs_of(h->inp); pg.in_ps = (rows + 1) * pg.in_cs;
+  pg.wbuf_off[0] = off_w0; pg.wbuf_off[1] = off_i;
+  pg.pol_off = off_w0; pg.pol_cs = pol_cs;
+  pg.val_off = off_w0 + (int)pol_floats; pg.val_cs = val_cs;
+  const int off_h1 = pg.val_off + (int)val_floats, off_h2 = off_h1 + (int)pieces_floats(hidden);
+  const int cs_w = cs_of(W), ps_w = (rows + 1) * cs_w, cs_h = cs_of(hidden), ps_h = (rows + 1) * cs_h;
+  struct Place { int off, cs, ps; };
+  pg.zero_at_op = n_trunk; pg.n_zero = 6; pg.zero_len = cs_h;
+  for (int piece = 0; piece < 3; ++piece) {
+    pg.zero_off[piece] = off_h1 + piece * ps_h + rows * cs_h;
+    pg.zero_off[3 + piece] = off_h2 + piece * ps_h + rows * cs_h;
+  }
+  const Place in_pl{off_i, pg.in_cs, pg.in_ps}, a_pl{off_a, cs_w, ps_w}, b_pl{off_b, cs_w, ps_w};
+  const Place h1_pl{off_h1, cs_h, ps_h}, h2_pl{off_h2, cs_h, ps_h};
+  const Place pol_pl{pg.pol_off, pg.pol_cs, 0}, val_pl{pg.val_off, pg.val_cs, 0};
+  const Place trunk_out = (n_trunk - 1) & 1 ? b_pl : a_pl, trunk_other = (n_trunk - 1) & 1 ? a_pl : b_pl;
+  for (int i = 0; i < n_ops; ++i) {
+    const ConvOp& op = h->ops[i];
+    const PackedConv& pc = h->convs[i];
+    Fused16Op& f = pg.ops[i];
+    if (op.src1 >= 0 || op.res >= 0) return;                     // a ConvNet has neither
+    Place src, dst;
+    if (i < n_trunk) {
+      src = i == 0 ? in_pl : ((i - 1) & 1 ? b_pl : a_pl);
+      dst = i & 1 ? b_pl : a_pl;
+    } else {
+      const int hidx = i - n_trunk;                              // 0, 1: policy head; 2..5: value head
+      switch (hidx) {
+        case 0: src = trunk_out; dst = trunk_other; break;
+        case 1: src = trunk_other; dst = pol_pl; break;
+        case 2: src = trunk_out; dst = h1_pl; break;
+        case 3: src = h1_pl; dst = h2_pl; break;
+        case 4: src = h2_pl; dst = h1_pl; break;
+        default: src = h1_pl; dst = val_pl; break;
+      }
+    }
+    f.w = pc.dev16;
+    f.off0 = src.off; f.cs0 = src.cs; f.ps0 = src.ps; f.kg0 = pc.kg0_32;
+    f.off1 = -1; f.cs1 = 0; f.ps1 = 0; f.kg1 = 0;
+    f.offd = dst.off; f.csd = dst.cs; f.psd = dst.ps;
+    f.offr = -1; f.csr = 0; f.psr = 0;
+    f.ntiles = pc.coutp / 16; f.act = op.act;
+    f.w_chunks = ntaps * pc.kg0_32 * 3 * 64;
+    // the K groups a layer reads must exist in its source rows
+    if (f.kg0 * 16 > f.cs0) return;
+    const size_t wf = (size_t)f.ntiles * f.w_chunks * 4;
+    if (i >= 1 && i < n_trunk) {            // layer 1 into buffer 0 (the input still sits in buffer 1), then alternating
+      f.w_lds = 1; f.w_slot = (i - 1) & 1; f.w_after_barrier = 0;
+    } else if (i >= n_trunk && wf <= region_i && wf <= (size_t)FUSED16_WREGS * FUSED_THREADS * 4) {
+      // head layers: buffer 0 is their activations' home, so all of them use buffer 1, written once the layer before is done
+      f.w_lds = 1; f.w_slot = 1; f.w_after_barrier = 1;
+    } else {
+      f.w_lds = 0; f.w_slot = 0; f.w_after_barrier = 0;
+    }
+  }
+  const size_t bytes = off * sizeof(float);
+  const hipError_t e = nd.hex
+      ? hipFuncSetAttribute((const void*)fused16_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+      : hipFuncSetAttribute((const void*)fused16_net_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return; }
+  Fused16Program* dev = nullptr;
+  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return;
+  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return; }
+  h->fused16_dev = dev;
+  h->fused16_grid = grid;
+  h->fused16_lds_bytes = bytes;
+}
 }  // namespace
 
 extern "C" {
@@ -1079,8 +1525,9 @@ void nz_boardnet_destroy(nz_boardnet* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (float* b : h->buffers) (void)hipFree(b);
-  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
+  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); if (c.dev16) (void)hipFree(c.dev16); }
   if (h->fused_dev) (void)hipFree(h->fused_dev);
+  if (h->fused16_dev) (void)hipFree(h->fused16_dev);
   delete h;
 }
 
@@ -1129,9 +1576,10 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   if (!h || !weights) return NZ_ERR_ARG;
   B_HIP(h, hipSetDevice(h->device));
   B_HIP(h, hipDeviceSynchronize());
-  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); }
+  for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); if (c.dev16) (void)hipFree(c.dev16); }
   h->convs.clear(); h->ops.clear(); h->flops = 0; h->ready = false;
   if (h->fused_dev) { (void)hipFree(h->fused_dev); h->fused_dev = nullptr; }
+  if (h->fused16_dev) { (void)hipFree(h->fused16_dev); h->fused16_dev = nullptr; }
   const nz_net_desc& nd = h->net;
   const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
   const int vact = nd.value_activation == NZ_ACT_RELU ? 1 : 2;
@@ -1197,6 +1645,7 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   if (!ok) return bfail(h, NZ_ERR_HIP, "weight upload failed");
   h->policy_buf = 5; h->value_buf = vsrc;
   build_fused(h, cur);
+  build_fused16(h);
   h->ready = true;
   return NZ_OK;
 }
@@ -1234,6 +1683,16 @@ static nz_status forward_impl(nz_boardnet* h, const float* images_dev, int32_t n
   if (images_dev != nullptr)        // else: the caller filled the input rows itself (nz_boardnet_input_rows)
     hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(blocks), dim3(256), 0, s, images_dev, h->buffers[0], n_dev, n,
                        h->net.in_channels, h->inp, h->hw);
+  if (h->fused16_dev != nullptr && h->use_fused) {  // one launch, on the BF16 matrix cores (three-way split arithmetic)
+    if (h->net.hex)
+      hipLaunchKernelGGL(fused16_net_kernel<true>, dim3(h->fused16_grid), dim3(FUSED_THREADS), h->fused16_lds_bytes, s,
+                         h->fused16_dev, h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
+    else
+      hipLaunchKernelGGL(fused16_net_kernel<false>, dim3(h->fused16_grid), dim3(FUSED_THREADS), h->fused16_lds_bytes, s,
+                         h->fused16_dev, h->buffers[0], h->inp, n_dev, n, logits_dev, probs_dev, value_dev);
+    B_HIP(h, hipGetLastError());
+    return NZ_OK;
+  }
   if (h->fused_dev != nullptr && h->use_fused) {    // every layer, the softmax and the value in one launch (activations in LDS)
     if (h->net.hex)
       hipLaunchKernelGGL(fused_net_kernel<true>, dim3(h->fused_grid), dim3(FUSED_THREADS), h->fused_lds_bytes, s, h->fused_dev,

@@ -253,9 +253,10 @@ def test_wide_layers_equal_the_oracle(arch, cin, planes, rows, cols, width, dept
     ("convnet", False, 5, 5, 32, 8, 1024), ("convnet", True, 5, 5, 32, 8, 333), ("resnet", False, 5, 5, 32, 2, 37),
     ("recurrent", False, 5, 5, 32, 2, 640), ("convnet", False, 10, 10, 32, 3, 70), ("resnet", False, 6, 5, 48, 2, 100)])
 def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, cols, width, depth, n):
-    """fused_net_kernel (all layers + softmax + value in one launch, activations in LDS, rows = (position, cell)) against
-    the per-layer kernels: the SAME floats (same MFMA, same K order; an off-board tap adds an exact zero), at ragged batch
-    sizes, with the batch size in device memory, for every architecture; and against the oracle within 1e-5."""
+    """The one-launch network (all layers + softmax + value in one launch, activations in LDS, rows = (position, cell))
+    against the per-layer kernels: fused_net_kernel gives the SAME floats (same MFMA, same K order; an off-board tap adds
+    an exact zero), fused16_net_kernel (ConvNets) the same within 5e-6; at ragged batch sizes, with the batch size in
+    device memory, for every architecture; and against the oracle within 1e-5."""
     import torch
     from scipy.special import softmax
     from nuzero_amd.boardnet import BoardNet
@@ -280,7 +281,14 @@ def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, col
     pf, vf, lf = net.forward(xd, want_logits=True)
     net.fused(False)
     pu, vu, lu = net.forward(xd, want_logits=True)
-    assert torch.equal(lf, lu) and torch.equal(pf, pu) and torch.equal(vf, vu)
+    if arch == "convnet":
+        # ConvNets run the one-launch form on the BF16 matrix cores (three-way split, six of nine piece products): the
+        # arithmetic of the Tic-Tac-Toe network, as accurate as float32 but not the per-layer kernels' rounding
+        scale = lu.abs().amax(dim=1, keepdim=True) + 1.0
+        assert float(((lf - lu).abs() / scale).max()) < 5e-6 and float((pf - pu).abs().max()) < 5e-6
+        assert float((vf - vu).abs().max()) < 5e-6
+    else:
+        assert torch.equal(lf, lu) and torch.equal(pf, pu) and torch.equal(vf, vu)
     net.fused(True)
     m = max(1, n // 3)                                   # live batch size on the device, smaller than the launch
     n_dev = torch.tensor([m], dtype=torch.int32, device="cuda")
