@@ -899,18 +899,24 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 
   int rt_cached = -1, srow[ntaps];
   const int zrow_index = prog->zrow_index;              // every buffer's row of zeros
+  // a layer's descriptor is fetched two layers ahead (a chain of scalar loads from memory costs a microsecond when waited for)
+  const int zero_at_op = prog->zero_at_op, n_zero = prog->n_zero, zero_len = prog->zero_len;
+  const int wbuf_off0 = prog->wbuf_off[0], wbuf_off1 = prog->wbuf_off[1];
+  Fused16Op d0 = n_ops > 0 ? prog->ops[0] : Fused16Op{}, d1 = n_ops > 1 ? prog->ops[1] : Fused16Op{};
   for (int o = 0; o < n_ops; ++o) {
-    const Fused16Op op = prog->ops[o];
-    if (o == prog->zero_at_op) {                            // (the previous layer's barrier is behind us; the first reader is two layers on)
-      for (int i = tid; i < prog->n_zero * prog->zero_len; i += FUSED_THREADS)
-        lds[prog->zero_off[i / prog->zero_len] + i % prog->zero_len] = 0.f;
+    const Fused16Op op = d0, next = d1;       // both read from memory at least a layer ago
+    d0 = d1;
+    if (o + 2 < n_ops) d1 = prog->ops[o + 2];
+    if (o == zero_at_op) {                            // (the previous layer's barrier is behind us; the first reader is two layers on)
+      for (int i = tid; i < n_zero * zero_len; i += FUSED_THREADS)
+        lds[prog->zero_off[i / zero_len] + i % zero_len] = 0.f;
     }
-    const bool next_lds = o + 1 < n_ops && prog->ops[o + 1].w_lds;
+    const bool next_lds = o + 1 < n_ops && next.w_lds;
     u32x4 wreg[FUSED16_WREGS];
-    if (next_lds) fetch_weights16(prog->ops[o + 1], wreg, tid);
+    if (next_lds) fetch_weights16(next, wreg, tid);
     const int kgt = op.kg0 + op.kg1;
     const int n_jobs = row_tiles * op.ntiles;
-    const float* wbuf = lds + prog->wbuf_off[op.w_slot];
+    const float* wbuf = lds + (op.w_slot ? wbuf_off1 : wbuf_off0);
     for (int job = wave; job < n_jobs; job += FUSED_WAVES) {
       const int rt = job / op.ntiles, ct = job - rt * op.ntiles;
       if (rt != rt_cached) {
@@ -972,11 +978,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 #ifdef NZ_FUSED_STAMPS
     if (o < 32) FSTAMP(tk_job[o]);
 #endif
-    if (next_lds && !prog->ops[o + 1].w_after_barrier)
-      store_weights16(prog->ops[o + 1], lds + prog->wbuf_off[prog->ops[o + 1].w_slot], wreg, tid);
+    float* const next_wbuf = lds + (next.w_slot ? wbuf_off1 : wbuf_off0);
+    if (next_lds && !next.w_after_barrier) store_weights16(next, next_wbuf, wreg, tid);
     __syncthreads();
-    if (next_lds && prog->ops[o + 1].w_after_barrier) {
-      store_weights16(prog->ops[o + 1], lds + prog->wbuf_off[prog->ops[o + 1].w_slot], wreg, tid);
+    if (next_lds && next.w_after_barrier) {
+      store_weights16(next, next_wbuf, wreg, tid);
       __syncthreads();
     }
 #ifdef NZ_FUSED_STAMPS
