@@ -815,20 +815,38 @@ template <int NTAPS, int KGT, bool WLDS>
 __device__ __forceinline__ void conv16_job(f32x4& acc, const float* __restrict__ lds, const int (&srow)[NTAPS], int off0,
                                            int cs0, int ps0, int kq, const float* __restrict__ wl,
                                            const uint32_t* __restrict__ wg) {
+  constexpr int STEPS = NTAPS * KGT;
+  constexpr int AHEAD = WLDS ? 0 : 3;         // weights read from L2: their loads run three steps ahead of the MFMAs
+  u32x4 bq[AHEAD + 1][3];
+  if constexpr (!WLDS) {
+#pragma unroll
+    for (int st = 0; st < AHEAD && st < STEPS; ++st)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) bq[st][piece] = *((gptr4u)(wg + (st * 3 + piece) * 256));
+  }
 #pragma unroll
   for (int tap = 0; tap < NTAPS; ++tap) {
     const int rbase = off0 + srow[tap] * cs0, sw = (srow[tap] >> 2) & 3;
 #pragma unroll
     for (int kg = 0; kg < KGT; ++kg) {
+      const int st = tap * KGT + kg;
       const int a0 = rbase + (((kg * 4 + kq) ^ sw) << 2);
-      u32x4 a[3], b[3];
+      u32x4 a[3];
 #pragma unroll
-      for (int piece = 0; piece < 3; ++piece) {
-        a[piece] = *reinterpret_cast<const u32x4*>(lds + a0 + piece * ps0);
-        if constexpr (WLDS) b[piece] = *reinterpret_cast<const u32x4*>(wl + ((tap * KGT + kg) * 3 + piece) * 256);
-        else b[piece] = *((gptr4u)(wg + ((tap * KGT + kg) * 3 + piece) * 256));
+      for (int piece = 0; piece < 3; ++piece) a[piece] = *reinterpret_cast<const u32x4*>(lds + a0 + piece * ps0);
+      if constexpr (WLDS) {
+        u32x4 b[3];
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) b[piece] = *reinterpret_cast<const u32x4*>(wl + (st * 3 + piece) * 256);
+        step16(acc, a, b);
+      } else {
+        if (st + AHEAD < STEPS) {
+#pragma unroll
+          for (int piece = 0; piece < 3; ++piece)
+            bq[(st + AHEAD) % (AHEAD + 1)][piece] = *((gptr4u)(wg + ((st + AHEAD) * 3 + piece) * 256));
+        }
+        step16(acc, a, bq[st % (AHEAD + 1)]);
       }
-      step16(acc, a, b);
     }
   }
 }
