@@ -1418,6 +1418,7 @@ void build_fused(nz_boardnet* h, int trunk_out) {
 // [zeros][input pieces -- after the first layer: weight buffer 1][weight buffer 0][activations A][activations B]; the
 // heads read their weights straight from L2 and keep their buffers (logits, value plane, two hidden buffers) in weight
 // buffer 0, which the trunk no longer needs by then.
+bool build_fused16_for(nz_boardnet* h, int p_max);
 void build_fused16(nz_boardnet* h) {
   static const int force = getenv("NZ_BOARDNET_FUSED16") ? atoi(getenv("NZ_BOARDNET_FUSED16")) : -1;   // tuning experiments
   const nz_net_desc& nd = h->net;
@@ -1428,8 +1429,17 @@ void build_fused16(nz_boardnet* h) {
     if (!pc.dev16) return;
   int n_cu = 0;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || n_cu <= 0) return;
-  const int grid = h->max_batch < n_cu ? h->max_batch : n_cu;
-  const int p_max = (h->max_batch + grid - 1) / grid;
+  // positions per workgroup: an even share of the largest batch over the CUs if that fits in LDS, else as many as fit (the
+  // grid then has more workgroups than CUs: they take the CUs in turn)
+  const int p_even = (h->max_batch + n_cu - 1) / n_cu;
+  for (int p_max = p_even; p_max >= 1; --p_max)
+    if (build_fused16_for(h, p_max)) return;
+}
+
+bool build_fused16_for(nz_boardnet* h, int p_max) {
+  const nz_net_desc& nd = h->net;
+  const int n_ops = (int)h->ops.size(), n_trunk = n_ops - 6;
+  const int grid = (h->max_batch + p_max - 1) / p_max;
   const int rows = p_max * h->hw;                               // rows past the last one are never read or written
   const int ntaps = nd.hex ? 7 : 9;
   auto cs_of = [](int channels) { return (channels + 31) / 32 * 16; };           // floats per row and piece
@@ -1446,7 +1456,7 @@ void build_fused16(nz_boardnet* h) {
     const PackedConv& pc = h->convs[i];
     wslot = std::max(wslot, (size_t)(pc.coutp / 16) * ntaps * (pc.kg0_32 + pc.kg1_32) * 3 * 64 * 4);
   }
-  if (wslot > (size_t)FUSED16_WREGS * FUSED_THREADS * 4) return;
+  if (wslot > (size_t)FUSED16_WREGS * FUSED_THREADS * 4) return false;
   const size_t in_floats = pieces_floats(h->inp);
   const size_t region_i = std::max(in_floats, wslot);
   const int off_i = (int)off; off += region_i;
@@ -1464,7 +1474,7 @@ void build_fused16(nz_boardnet* h) {
   const int off_a = (int)off; off += pieces_floats(W);
   const int off_b = (int)off; off += pieces_floats(W);
   off = (off + 3) / 4 * 4;
-  if (off > budget) return;
+  if (off > budget) return false;
   pg.lds_floats = (int32_t)off;
   // (the staged layers leave finite weights in the first `wslot` floats of weight buffer 0 before the heads move in)
   pg.clear_from = off_w0 + (n_trunk > 1 ? (int)wslot : 0);
@@ -1491,7 +1501,7 @@ void build_fused16(nz_boardnet* h) {
     const ConvOp& op = h->ops[i];
     const PackedConv& pc = h->convs[i];
     Fused16Op& f = pg.ops[i];
-    if (op.src1 >= 0 || op.res >= 0) return;                     // a ConvNet has neither
+    if (op.src1 >= 0 || op.res >= 0) return false;                     // a ConvNet has neither
     Place src, dst;
     if (i < n_trunk) {
       src = i == 0 ? in_pl : ((i - 1) & 1 ? b_pl : a_pl);
@@ -1515,7 +1525,7 @@ void build_fused16(nz_boardnet* h) {
     f.ntiles = pc.coutp / 16; f.act = op.act;
     f.w_chunks = ntaps * pc.kg0_32 * 3 * 64;
     // the K groups a layer reads must exist in its source rows
-    if (f.kg0 * 16 > f.cs0) return;
+    if (f.kg0 * 16 > f.cs0) return false;
     const size_t wf = (size_t)f.ntiles * f.w_chunks * 4;
     if (i >= 1 && i < n_trunk) {            // layer 1 into buffer 0 (the input still sits in buffer 1), then alternating
       f.w_lds = 1; f.w_slot = (i - 1) & 1; f.w_after_barrier = 0;
@@ -1530,13 +1540,14 @@ void build_fused16(nz_boardnet* h) {
   const hipError_t e = nd.hex
       ? hipFuncSetAttribute((const void*)fused16_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
       : hipFuncSetAttribute((const void*)fused16_net_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) { (void)hipGetLastError(); return; }
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
   Fused16Program* dev = nullptr;
-  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return;
-  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return; }
+  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return false;
+  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return false; }
   h->fused16_dev = dev;
   h->fused16_grid = grid;
   h->fused16_lds_bytes = bytes;
+  return true;
 }
 }  // namespace
 
