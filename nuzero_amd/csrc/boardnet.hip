@@ -885,12 +885,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
   for (int i = 0; i < 32; ++i) tk_k[i] = 0;
 #endif
 
+#ifdef NZ_FUSED_STAMPS
+  unsigned long long tk_args = 0; asm volatile("" :: "s"(np), "s"(hw), "s"(n_ops)); FSTAMP(tk_args);
+#endif
   // K groups reach past a narrow layer's channels and row tiles past the last row (zero weights, discarded rows): what
   // they read must be numbers, so everything starts as zeros
   for (int i = prog->clear_from + tid * 4; i < prog->lds_floats; i += FUSED_THREADS * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < 3 * prog->in_cs; i += FUSED_THREADS)     // the input's row of zeros
     lds[prog->in_off + (i / prog->in_cs) * prog->in_ps + prog->zrow_index * prog->in_cs + i % prog->in_cs] = 0.f;
   __syncthreads();
+#ifdef NZ_FUSED_STAMPS
+  unsigned long long tk_clear = 0; FSTAMP(tk_clear);
+#endif
   {   // this workgroup's input rows, split into pieces (global row of (position n, cell c): ((n >> 4) * hw + c) * 16 + (n & 15))
     const int cs = prog->in_cs, ps = prog->in_ps;
     const int chunks = in_channels >> 3;                    // eight channels = one 16-byte chunk of a piece
@@ -907,6 +913,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
       *reinterpret_cast<u32x4*>(d + 2 * ps) = q2;
     }
   }
+#ifdef NZ_FUSED_STAMPS
+  unsigned long long tk_split = 0; FSTAMP(tk_split);
+#endif
   if (n_ops > 0 && prog->ops[0].w_lds) {
     u32x4 wreg[FUSED16_WREGS];
     fetch_weights16(prog->ops[0], wreg, tid);
@@ -1051,7 +1060,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 #ifdef NZ_FUSED_STAMPS
   FSTAMP(tk_fin);
   if (blockIdx.x == 0 && (tid == 0 || tid == FUSED_THREADS - 64)) {
-    printf("fused16 wg0 wave %d np %d rows %d: input %llu finalize %llu\n", wave, np, rows, tk_in, tk_fin);
+    printf("fused16 wg0 wave %d np %d rows %d: args %llu clear %llu split %llu rest-of-input %llu finalize %llu\n", wave, np, rows, tk_args, tk_clear, tk_split, tk_in, tk_fin);
     for (int o = 0; o < n_ops && o < 32; ++o) printf("  wave %d op %d kg %d ntiles %d wlds %d slot %d: jobs %llu (k loop %llu) barrier+stage %llu\n", wave, o, prog->ops[o].kg0, prog->ops[o].ntiles, prog->ops[o].w_lds, prog->ops[o].w_slot, tk_job[o], tk_k[o], tk_bar[o]);
   }
 #endif
