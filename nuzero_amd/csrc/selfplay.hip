@@ -50,9 +50,13 @@ __device__ __forceinline__ void expanded_near_root(RootCache& rc, Arena t, int r
 
 constexpr int LDS_TAB = 960;     // entries of the (sqrt, bias) tables kept in LDS: enough for 100 simulations per move
 
-// The tree phase runs on the first four waves (16 games x 16 lanes); the network phase on all eight.
+// The tree phase: 16 games x 16 lanes, two games per wave (the first two DPP rows of each of the eight waves; with four
+// games per wave the rows that are in different branches -- expansion, descent, end of move -- take turns).
 constexpr int TREE_THREADS = POS * LANES_PER_GAME;
-static_assert(TREE_THREADS <= NET_THREADS, "the tree phase's lanes are a prefix of the workgroup");
+static_assert(NET_THREADS == 2 * TREE_THREADS, "two of a wave's four rows carry a game");
+__device__ __forceinline__ bool tree_lane(int tid) { return (tid & 32) == 0; }
+__device__ __forceinline__ int tree_slot(int tid) { return (tid >> 6) * 2 + ((tid >> 4) & 1); }      // game slot = network row
+__device__ __forceinline__ int tree_index(int tid) { return tree_slot(tid) * LANES_PER_GAME + (tid & 15); }   // into park_lane
 // Tree-phase state of one row (game slot); see `park` below.
 struct RowState {
   bool alive = false, pending = false;
@@ -167,8 +171,8 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   {
     const TreeParams& p = kernel_args().p;
     for (int i = threadIdx.x; i < LDS_TAB && i < p.tab_len; i += NET_THREADS) tab[i] = make_double2(p.sqrt_tab[i], p.bias_tab[i]);
-    const int tid = threadIdx.x, slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);
-    if (tid < TREE_THREADS) {
+    const int tid = threadIdx.x, slot = tree_slot(tid), sub = tid & (LANES_PER_GAME - 1);
+    if (tree_lane(tid)) {
       const int gslot = blockIdx.x * POS + slot;
       RootCache rc0;
       root_cache_load(rc0, arena_of(p, gslot < p.n_slots ? gslot : 0), 0, sub);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
       st0.alive = gslot < p.n_slots && gslot < p.n_games;
       st0.g = gslot;                                     // game being played in this slot
       st0.sims_left = p.sims;
-      park(st0, rc0, park_row, park_lane, slot, sub, tid);
+      park(st0, rc0, park_row, park_lane, slot, sub, tree_index(tid));
     }
   }
   unsigned long long t_tree = 0, t_net = 0, n_cycles = 0, t_begin = 0, t0 = 0, t_finish = 0;
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     // (per-lane indices and the arguments are re-derived here every cycle: loop-invariant values would be kept in
     // registers across the network phase)
     const int tid = opaque(threadIdx.x);
-    const int slot = tid / LANES_PER_GAME;               // game slot in the tile = network row
+    const int slot = tree_slot(tid);                     // game slot in the tile = network row
     const int sub = tid & (LANES_PER_GAME - 1);
     const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
     const SelfplayArgs& ka = kernel_args();
@@ -204,10 +208,10 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
       __syncthreads();
     }
     bool row_alive = false, row_pending = false;
-    if (tid < TREE_THREADS) {                            // waves 4-7 only work in the network phase
+    if (tree_lane(tid)) {                                // lanes 32-63 of every wave only work in the network phase
     RowState st;
     RootCache rc;
-    unpark(st, rc, park_row, park_lane, slot, sub, tid);
+    unpark(st, rc, park_row, park_lane, slot, sub, tree_index(tid));
     const Arena t = arena_of(p, gslot < p.n_slots ? gslot : 0);
     bool& alive = st.alive;
     bool& pending = st.pending;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     if constexpr (STAMPS) {
       if (sub == 0) atomicMax(&s_max_sims, cyc_sims);
     }
-    park(st, rc, park_row, park_lane, slot, sub, tid);
+    park(st, rc, park_row, park_lane, slot, sub, tree_index(tid));
     row_alive = alive;
     row_pending = pending;
     }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   const SelfplayArgs& ea = kernel_args();
   const TreeParams& p = ea.p;
   unsigned long long* const stamps = ea.stamps;
-  const int tid = opaque(threadIdx.x), slot = tid / LANES_PER_GAME, sub = tid & (LANES_PER_GAME - 1);   // (not the prologue's copies)
+  const int tid = opaque(threadIdx.x), slot = tree_slot(tid), sub = tid & (LANES_PER_GAME - 1);   // (not the prologue's copies)
   const int gslot = blockIdx.x * POS + slot;
   if constexpr (STAMPS) {
     if (tid == 0) {
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     }
   }
 
-  if (tid < TREE_THREADS && gslot < p.n_slots && sub == 0) {
+  if (tree_lane(tid) && gslot < p.n_slots && sub == 0) {
     p.alive[gslot] = 0;
     p.pending[gslot] = -1;
     p.n_root_children[gslot] = 0;
