@@ -166,7 +166,8 @@ class Gamer:
             from .scs import ScsGameConfig, ScsSelfPlay
             if not game_args:
                 raise ValueError("SCS needs game_args = [path of the game config]")
-            self.scs_config = ScsGameConfig(game_args[0])
+            # ([config path, map_seed]: a "Randomized" config with the map the reference draws after np.random.seed(map_seed))
+            self.scs_config = ScsGameConfig(game_args[0], *game_args[1:2])
             # `concurrent_games` trees play the round's `num_games` games: a tree whose game has ended starts the round's
             # next one (the reference's ActorPool of num_actors Gamers over num_games_per_step games, AlphaZero.py:525-577;
             # games are independent and seeded by their index, so which tree plays a game does not change it)

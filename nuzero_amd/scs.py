@@ -1,7 +1,7 @@
 """SCS rules on the GPU as batch operators (C ABI nz_scs_*), plus the game-config loader.
 
 `ScsGameConfig` reads the reference's YAML game configs (Games/SCS/Game_configs/*.yml, parsed
-by SCS_Game.load_game_from_config, SCS_Game.py:1570-1779) with the "Detailed" map and
+by SCS_Game.load_game_from_config, SCS_Game.py:1570-1779) with the "Detailed" (or seeded "Randomized") map and
 victory-point methods; `ScsBatch` runs G independent games on the device: step, legal-move
 mask (possible_actions, :395-484), state image (generate_state, :1348-1505).
 """
@@ -16,8 +16,36 @@ from . import _lib
 from ._lib import lib
 
 
+def randomized_map(d, rows, cols, p1_last, p2_first, seed):
+    """What SCS_Game.load_game_from_config draws for "Randomized" maps / victory points (SCS_Game.py:1678-1738) when
+    numpy's global stream was seeded with `seed` just before: the sections in file order, a tile's terrain by
+    np.random.choice(terrain_types, p=distribution) row by row, a victory point by np.random.choice(range(rows)) and
+    np.random.choice(range(columns of the player's side)), redrawn while it repeats an earlier one.  Returns
+    (terrain id map or None, (p1 points, p2 points) or None)."""
+    rs = np.random.RandomState(seed)
+    ids = [int(p["id"]) for p in d["Terrain"].values()]          # terrain_types: the Terrain section's order
+    tmap = vps = None
+    for section, values in d.items():
+        if section == "Map" and values["creation_method"] == "Randomized":
+            dist = values.get("distribution") or [1 / len(ids)] * len(ids)
+            tmap = [[ids[int(rs.choice(len(ids), p=dist))] for _ in range(cols)] for _ in range(rows)]
+        elif section == "Victory_points" and values["creation_method"] == "Randomized":
+            vps = ([], [])
+            col_ranges = (range(p1_last + 1), range(p2_first, cols))
+            for side, key in enumerate(("p1", "p2")):
+                for _ in range(int(values["number_vp"][key])):
+                    pt = (int(rs.choice(range(rows))), int(rs.choice(col_ranges[side])))
+                    while pt in vps[side]:
+                        pt = (int(rs.choice(range(rows))), int(rs.choice(col_ranges[side])))
+                    vps[side].append(pt)
+    return tmap, vps
+
+
 class ScsGameConfig:
-    def __init__(self, path_or_dict):
+    def __init__(self, path_or_dict, map_seed=None):
+        """`map_seed`: for configs with "Randomized" maps or victory points -- the map SCS_Game(config) builds when
+        np.random.seed(map_seed) was called just before (the reference draws from numpy's global stream at load time, a
+        new map per game object; here one map per config object, i.e. per engine and round)."""
         if isinstance(path_or_dict, dict):
             d = path_or_dict
         else:
@@ -25,9 +53,22 @@ class ScsGameConfig:
                 d = yaml.safe_load(f)
         self.rows, self.cols = int(d["Board_dimensions"]["rows"]), int(d["Board_dimensions"]["columns"])
         self.turns, self.stacking = int(d["Turns"]), int(d["Stacking_limit"])
+        mid = self.cols // 2                    # the board's two sides (define_board_sides, :1140-1158)
+        if self.cols % 2:
+            side_p1_last, side_p2_first = mid - 1, mid + 1
+        else:
+            side_p1_last, side_p2_first = max(0, mid - 2), min(self.cols - 1, mid + 1)
         if d["Map"]["creation_method"] != "Detailed" or d["Victory_points"]["creation_method"] != "Detailed":
-            raise NotImplementedError("only 'Detailed' maps and victory points (the 'Randomized' methods draw "
-                                      "from numpy's global stream at load time, SCS_Game.py:1683-1738)")
+            if map_seed is None:
+                raise NotImplementedError("'Randomized' maps / victory points draw from numpy's global stream at load "
+                                          "time (SCS_Game.py:1683-1738): pass map_seed")
+            rmap, rvps = randomized_map(d, self.rows, self.cols, side_p1_last, side_p2_first, map_seed)
+            d = dict(d)
+            if rmap is not None:
+                d["Map"] = {"creation_method": "Detailed", "map_configuration": rmap}
+            if rvps is not None:
+                d["Victory_points"] = {"creation_method": "Detailed",
+                                       "vp_locations": {"p1": [list(p) for p in rvps[0]], "p2": [list(p) for p in rvps[1]]}}
         units = {int(p["id"]): p for p in d["Units"].values()}
         terrain = {int(p["id"]): p for p in d["Terrain"].values()}
         tmap = np.asarray(d["Map"]["map_configuration"])

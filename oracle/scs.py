@@ -29,9 +29,10 @@ class Unit:
 
 
 class ScsConfig:
-    """The game description of SCS_Game.load_game_from_config (:1570-1779), Detailed methods only."""
+    """The game description of SCS_Game.load_game_from_config (:1570-1779).  "Randomized" maps and victory points
+    (:1678-1738) need `map_seed`: what the reference draws from numpy's global stream after np.random.seed(map_seed)."""
 
-    def __init__(self, path):
+    def __init__(self, path, map_seed=None):
         with open(path) as f:
             d = yaml.safe_load(f)
         self.rows, self.cols = d["Board_dimensions"]["rows"], d["Board_dimensions"]["columns"]
@@ -69,10 +70,27 @@ class ScsConfig:
                     row.append((u["attack"], u["defense"], u["movement"], loc))
                 self.schedule[p].append(row)
         terrain = {t["id"]: t for t in d["Terrain"].values()}
-        assert d["Map"]["creation_method"] == "Detailed" and d["Victory_points"]["creation_method"] == "Detailed"
+        map_ids = d["Map"].get("map_configuration")
+        vp = d["Victory_points"].get("vp_locations")
+        if d["Map"]["creation_method"] != "Detailed" or d["Victory_points"]["creation_method"] != "Detailed":
+            assert map_seed is not None, "Randomized methods draw from numpy's global stream: pass map_seed"
+            rs = np.random.RandomState(map_seed)
+            ids = [t["id"] for t in d["Terrain"].values()]            # self.terrain_types, in the section's order (:1665-1676)
+            for section, values in d.items():                        # the sections in file order (:1582)
+                if section == "Map" and values["creation_method"] == "Randomized":          # :1679-1690
+                    dist = values.get("distribution") or [1 / len(ids) for _ in ids]
+                    map_ids = [[ids[rs.choice(len(ids), p=dist)] for _ in range(self.cols)] for _ in range(self.rows)]
+                elif section == "Victory_points" and values["creation_method"] == "Randomized":   # :1709-1738
+                    vp = {"p1": [], "p2": []}
+                    cols_of = {"p1": range(p1_last + 1), "p2": range(p2_first, self.cols)}
+                    for key in ("p1", "p2"):
+                        for _ in range(values["number_vp"][key]):
+                            point = (int(rs.choice(range(self.rows))), int(rs.choice(cols_of[key])))
+                            while point in vp[key]:
+                                point = (int(rs.choice(range(self.rows))), int(rs.choice(cols_of[key])))
+                            vp[key].append(point)
         self.terrain = [[(terrain[t]["attack_modifier"], terrain[t]["defense_modifier"], terrain[t]["cost"])
-                         for t in row] for row in d["Map"]["map_configuration"]]
-        vp = d["Victory_points"]["vp_locations"]
+                         for t in row] for row in map_ids]
         self.vp = [[tuple(p) for p in vp["p1"]], [tuple(p) for p in vp["p2"]]]
         s = self.stacking
         # action planes (:147-180) and their borders

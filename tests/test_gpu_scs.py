@@ -12,13 +12,18 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 @pytest.mark.parametrize("name,n_games", [("mirrored_5x5", 48), ("late_reinforcements_5x5", 48),
                                           ("two_types_6x5", 48), ("ten_by_ten", 12), ("wide_arrival_10x10", 8),
-                                          ("reference_test_config", 12)])
+                                          ("reference_test_config", 12),
+                                          ("randomized_5x5@7", 24), ("randomized_10x10@2", 8)])
 def test_scs_device_rules_equal_oracle(name, n_games):
+    """(name@seed: a "Randomized" configuration of the reference with the map it draws after np.random.seed(seed) --
+    the maps themselves are pinned by tests/test_scs_oracle.py::test_randomized_maps_against_reference)"""
     from nuzero_amd.scs import ScsBatch, ScsGameConfig
     from oracle.scs import ScsConfig, ScsGame
+    name, _, map_seed = name.partition("@")
+    map_seed = int(map_seed) if map_seed else None
     path = os.path.join(GOLDEN, "scs_configs", name + ".yml")
-    ocfg = ScsConfig(path)
-    cfg = ScsGameConfig(path)
+    ocfg = ScsConfig(path, map_seed=map_seed)
+    cfg = ScsGameConfig(path, map_seed=map_seed)
     assert (cfg.planes, cfg.channels, cfg.num_actions) == (ocfg.planes, ocfg.channels, ocfg.num_actions)
     batch = ScsBatch(cfg, n_games)
     games = [ScsGame(ocfg) for _ in range(n_games)]

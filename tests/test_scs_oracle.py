@@ -96,3 +96,29 @@ def test_scs_search_against_reference():
                 for key in ("action", "root_visits", "root_value_sum", "child_actions", "child_visits",
                             "child_priors", "child_value_sums"):
                     assert mine[key] == theirs[key], (name, key)
+
+
+def test_randomized_maps_against_reference():
+    """"Randomized" maps and victory points (SCS_Game.py:1678-1738): what the genuine reference builds after
+    np.random.seed(seed) (tests/golden/scs_random_maps.json, made by make_golden_scs_random.py) equals what the oracle
+    and the product's host-side config build from map_seed=seed, for both of the reference's randomized configs."""
+    import json
+    from nuzero_amd.scs import ScsGameConfig
+    from oracle.scs import ScsConfig
+    with open(os.path.join(GOLDEN, "scs_random_maps.json")) as f:
+        gold = json.load(f)
+    assert set(gold) == {"randomized_5x5", "randomized_10x10"}
+    for name, cases in gold.items():
+        path = os.path.join(GOLDEN, "scs_configs", name + ".yml")
+        with pytest.raises(Exception):
+            ScsGameConfig(path)                               # no seed: refused, not guessed
+        seen = set()
+        for seed, want in cases.items():
+            oc = ScsConfig(path, map_seed=int(seed))
+            assert [[list(map(float, t)) for t in row] for row in oc.terrain] == want["terrain"], (name, seed)
+            assert [list(map(list, side)) for side in oc.vp] == want["vp"], (name, seed)
+            pc = ScsGameConfig(path, map_seed=int(seed))
+            assert np.array_equal(pc.terrain.reshape(oc.rows, oc.cols, 3), np.array(want["terrain"], np.float32))
+            assert pc.vp.tolist() == [list(p) for side in want["vp"] for p in side]
+            seen.add(json.dumps(want["terrain"]))
+        assert len(seen) == len(cases)                        # the seeds give different maps
