@@ -1428,10 +1428,11 @@ void build_fused(nz_boardnet* h, int trunk_out) {
 // heads read their weights straight from L2 and keep their buffers (logits, value plane, two hidden buffers) in weight
 // buffer 0, which the trunk no longer needs by then.
 bool build_fused16_for(nz_boardnet* h, int p_max);
+bool build_fused16_resnet(nz_boardnet* h, int p_max);
 void build_fused16(nz_boardnet* h) {
   static const int force = getenv("NZ_BOARDNET_FUSED16") ? atoi(getenv("NZ_BOARDNET_FUSED16")) : -1;   // tuning experiments
   const nz_net_desc& nd = h->net;
-  if (force == 0 || nd.arch != NZ_ARCH_CONVNET || (int)h->ops.size() > FUSED_MAX_OPS || h->inp % 8 != 0) return;
+  if (force == 0 || (nd.arch != NZ_ARCH_CONVNET && nd.arch != NZ_ARCH_RESNET) || (int)h->ops.size() > FUSED_MAX_OPS || h->inp % 8 != 0) return;
   const int n_ops = (int)h->ops.size(), n_trunk = n_ops - 6;     // first layer + num_blocks layers, then 2 + 4 head layers
   if (n_trunk < 1) return;
   for (const PackedConv& pc : h->convs)
@@ -1442,7 +1443,7 @@ void build_fused16(nz_boardnet* h) {
   // grid then has more workgroups than CUs: they take the CUs in turn)
   const int p_even = (h->max_batch + n_cu - 1) / n_cu;
   for (int p_max = p_even; p_max >= 1; --p_max)
-    if (build_fused16_for(h, p_max)) return;
+    if (nd.arch == NZ_ARCH_CONVNET ? build_fused16_for(h, p_max) : build_fused16_resnet(h, p_max)) return;
 }
 
 bool build_fused16_for(nz_boardnet* h, int p_max) {
@@ -1544,6 +1545,105 @@ bool build_fused16_for(nz_boardnet* h, int p_max) {
     } else {
       f.w_lds = 0; f.w_slot = 0; f.w_after_barrier = 0;
     }
+  }
+  const size_t bytes = off * sizeof(float);
+  const hipError_t e = nd.hex
+      ? hipFuncSetAttribute((const void*)fused16_net_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)
+      : hipFuncSetAttribute((const void*)fused16_net_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  Fused16Program* dev = nullptr;
+  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return false;
+  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return false; }
+  h->fused16_dev = dev;
+  h->fused16_grid = grid;
+  h->fused16_lds_bytes = bytes;
+  return true;
+}
+// The same for ResNets: three trunk buffers (a block reads its input again as the residual).  LDS, in floats:
+// [input pieces -- after the first layer: trunk buffers 2 and 3][the weight buffer][trunk buffer 1][logits][value plane];
+// one weight buffer only, so a layer's weights are stored once the layer before it is done (they travel from L2 under its
+// MFMAs all the same).  The head layers use the two trunk buffers that are free by then.
+bool build_fused16_resnet(nz_boardnet* h, int p_max) {
+  const nz_net_desc& nd = h->net;
+  const int n_ops = (int)h->ops.size(), n_trunk = n_ops - 6;
+  if (n_trunk < 1) return false;
+  const int grid = (h->max_batch + p_max - 1) / p_max;
+  const int rows = p_max * h->hw;
+  const int ntaps = nd.hex ? 7 : 9;
+  auto cs_of = [](int channels) { return (channels + 31) / 32 * 16; };
+  auto pieces_floats = [&](int channels) { return (size_t)3 * (rows + 1) * cs_of(channels); };
+  const size_t budget = 160 * 1024 / sizeof(float);
+  Fused16Program pg;
+  memset(&pg, 0, sizeof(pg));
+  pg.zrow_index = rows;
+  const int W = nd.width;
+  size_t wslot = 0;
+  for (int i = 1; i < n_ops; ++i) {
+    const PackedConv& pc = h->convs[i];
+    wslot = std::max(wslot, (size_t)(pc.coutp / 16) * ntaps * (pc.kg0_32 + pc.kg1_32) * 3 * 64 * 4);
+  }
+  if (wslot > (size_t)FUSED16_WREGS * FUSED_THREADS * 4) return false;
+  size_t off = 0;
+  const size_t act = pieces_floats(W);
+  const size_t region_i = std::max(pieces_floats(h->inp), 2 * act);
+  const int off_i = (int)off; off += region_i;
+  const int off_w0 = (int)off; off += wslot;
+  const int off_a = (int)off; off += act;
+  const int pol_cs = pad16(nd.policy_channels) + FUSED_PAD, val_cs = pad16(1) + FUSED_PAD;
+  const int off_pol = (int)off; off += ((size_t)rows * pol_cs + 3) / 4 * 4;
+  const int off_val = (int)off; off += ((size_t)rows * val_cs + 3) / 4 * 4;
+  if (off > budget) return false;
+  pg.lds_floats = (int32_t)off;
+  pg.clear_from = off_a;
+  pg.n_ops = n_ops;
+  pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
+  pg.planes = nd.policy_channels; pg.hex = nd.hex ? 1 : 0;
+  pg.in_off = off_i; pg.in_cs = cs_of(h->inp); pg.in_ps = (rows + 1) * pg.in_cs;
+  pg.wbuf_off[0] = off_w0; pg.wbuf_off[1] = off_w0;
+  pg.pol_off = off_pol; pg.pol_cs = pol_cs;
+  pg.val_off = off_val; pg.val_cs = val_cs;
+  const int cs_w = cs_of(W), ps_w = (rows + 1) * cs_w;
+  struct Place { int off, cs, ps; };
+  const Place in_pl{off_i, pg.in_cs, pg.in_ps};
+  const Place trunk[4] = {in_pl, {off_a, cs_w, ps_w}, {off_i, cs_w, ps_w}, {off_i + (int)act, cs_w, ps_w}};   // buffer ids 0..3
+  // buffers 2 and 3 take over the input's space: their rows of zeros are made when the first layer is done
+  pg.zero_at_op = 1; pg.n_zero = 6; pg.zero_len = cs_w;
+  for (int piece = 0; piece < 3; ++piece) {
+    pg.zero_off[piece] = trunk[2].off + piece * ps_w + rows * cs_w;
+    pg.zero_off[3 + piece] = trunk[3].off + piece * ps_w + rows * cs_w;
+  }
+  const int t_out = h->ops[n_trunk].src0;                        // the trunk's output buffer (what the policy head reads)
+  if (t_out < 1 || t_out > 3) return false;
+  int free_ids[2], nf = 0;
+  for (int b = 1; b <= 3; ++b)
+    if (b != t_out) free_ids[nf++] = b;
+  const Place pol_pl{off_pol, pol_cs, 0}, val_pl{off_val, val_cs, 0};
+  auto place_of = [&](int id, bool last_value) -> Place {         // buffer id of the per-layer form -> where it lives here
+    if (id >= 0 && id <= 3) return trunk[id];
+    if (id == 4) return trunk[free_ids[0]];                       // policy hidden
+    if (id == 5) return pol_pl;
+    if (last_value) return val_pl;
+    return trunk[free_ids[id == 6 ? 0 : 1]];                      // value chain 6, 7 (6 after the policy head is done with it)
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    const ConvOp& op = h->ops[i];
+    const PackedConv& pc = h->convs[i];
+    Fused16Op& f = pg.ops[i];
+    if (op.src1 >= 0 || !pc.dev16) return false;
+    const Place src = place_of(op.src0, false), dst = place_of(op.dst, i == n_ops - 1);
+    f.w = pc.dev16;
+    f.off0 = src.off; f.cs0 = src.cs; f.ps0 = src.ps; f.kg0 = pc.kg0_32;
+    f.off1 = -1; f.cs1 = 0; f.ps1 = 0; f.kg1 = 0;
+    f.offd = dst.off; f.csd = dst.cs; f.psd = dst.ps;
+    if (op.res >= 0) { const Place r = place_of(op.res, false); f.offr = r.off; f.csr = r.cs; f.psr = r.ps; }
+    else { f.offr = -1; f.csr = 0; f.psr = 0; }
+    f.ntiles = pc.coutp / 16; f.act = op.act;
+    f.w_chunks = ntaps * pc.kg0_32 * 3 * 64;
+    if (f.kg0 * 16 > f.cs0) return false;
+    const size_t wf = (size_t)f.ntiles * f.w_chunks * 4;
+    f.w_lds = i >= 1 && wf <= wslot ? 1 : 0;
+    f.w_slot = 0;
+    f.w_after_barrier = 1;
   }
   const size_t bytes = off * sizeof(float);
   const hipError_t e = nd.hex

@@ -255,7 +255,7 @@ def test_wide_layers_equal_the_oracle(arch, cin, planes, rows, cols, width, dept
 def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, cols, width, depth, n):
     """The one-launch network (all layers + softmax + value in one launch, activations in LDS, rows = (position, cell))
     against the per-layer kernels: fused_net_kernel gives the SAME floats (same MFMA, same K order; an off-board tap adds
-    an exact zero), fused16_net_kernel (ConvNets) the same within 5e-6; at ragged batch sizes, with the batch size in
+    an exact zero), fused16_net_kernel (ConvNets, ResNets) the same within 5e-6; at ragged batch sizes, with the batch size in
     device memory, for every architecture; and against the oracle within 1e-5."""
     import torch
     from scipy.special import softmax
@@ -281,8 +281,8 @@ def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, col
     pf, vf, lf = net.forward(xd, want_logits=True)
     net.fused(False)
     pu, vu, lu = net.forward(xd, want_logits=True)
-    if arch == "convnet":
-        # ConvNets run the one-launch form on the BF16 matrix cores (three-way split, six of nine piece products): the
+    if arch in ("convnet", "resnet"):
+        # ConvNets and ResNets run the one-launch form on the BF16 matrix cores (three-way split, six of nine piece products): the
         # arithmetic of the Tic-Tac-Toe network, as accurate as float32 but not the per-layer kernels' rounding
         scale = lu.abs().amax(dim=1, keepdim=True) + 1.0
         assert float(((lf - lu).abs() / scale).max()) < 5e-6 and float((pf - pu).abs().max()) < 5e-6
