@@ -1799,7 +1799,7 @@ int64_t nz_boardnet_flops(const nz_boardnet* h) { return h ? h->flops : 0; }
 nz_status nz_boardnet_fused(nz_boardnet* h, int32_t enable, int32_t* available) {
   if (!h) return NZ_ERR_ARG;
   if (enable >= 0) h->use_fused = enable != 0;
-  if (available) *available = h->fused_dev != nullptr ? 1 : 0;
+  if (available) *available = h->fused_dev != nullptr || h->fused16_dev != nullptr ? 1 : 0;
   return NZ_OK;
 }
 

@@ -251,7 +251,9 @@ def test_wide_layers_equal_the_oracle(arch, cin, planes, rows, cols, width, dept
 
 @pytest.mark.parametrize("arch,hexnet,rows,cols,width,depth,n", [
     ("convnet", False, 5, 5, 32, 8, 1024), ("convnet", True, 5, 5, 32, 8, 333), ("resnet", False, 5, 5, 32, 2, 37),
-    ("recurrent", False, 5, 5, 32, 2, 640), ("convnet", False, 10, 10, 32, 3, 70), ("resnet", False, 6, 5, 48, 2, 100)])
+    ("recurrent", False, 5, 5, 32, 2, 640), ("convnet", False, 10, 10, 32, 3, 70), ("resnet", False, 6, 5, 48, 2, 100),
+    # more positions than fit in LDS at an even share per CU: the BF16 one-launch grid is larger than the CU count
+    ("convnet", False, 5, 5, 32, 8, 2500), ("resnet", False, 5, 5, 32, 6, 1500)])
 def test_one_launch_network_equals_the_per_layer_kernels(arch, hexnet, rows, cols, width, depth, n):
     """The one-launch network (all layers + softmax + value in one launch, activations in LDS, rows = (position, cell))
     against the per-layer kernels: fused_net_kernel gives the SAME floats (same MFMA, same K order; an off-board tap adds
