@@ -29,7 +29,8 @@ Extra keys (N = 1)
   scs_config4       BASELINE.json configs[3]: SCS 5x5, ConvNet(32 filters x 8 layers, square convs), 200 sims/move,
                     1024 concurrent games, one whole round in the library (nz_scs_search_play)
   gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
-                    save_game for every game, statistics), games/s
+                    save_game for every game, statistics), games/s; with --rounds-in-flight N the sub-key
+                    play_forever_in_flight: the same worker in the trainer's asynchronous mode (Gamer.play_forever)
   rounds_in_flight_N  (only with --rounds-in-flight N) the same rounds with N engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
                     next round's workgroups take the compute units the current round's tail leaves idle), games/s --
                     the reference's asynchronous mode (Gamers that play_forever); NOT `value`, whose rounds run one
@@ -170,7 +171,7 @@ def rounds_in_flight(cfg, weights, games, n_round, device, iters, rounds=6, dept
             "engines": depth, "games_per_round": n_round, "concurrent_games_per_engine": games}
 
 
-def gamer_surface(cfg, weights, games, n_round, device, rounds=2):
+def gamer_surface(cfg, weights, games, n_round, device, rounds=2, in_flight=0):
     """The reference-shaped worker round: Gamer.play_games = search + ReplayBuffer.save_game for every game + the six
     statistics per game, with the replay buffer on the device; then one training batch is drawn."""
     import torch
@@ -199,6 +200,26 @@ def gamer_surface(cfg, weights, games, n_round, device, rounds=2):
            "buffer_positions": rb.len(), "sample_2048_ms": (time.perf_counter() - t1) * 1e3,
            "includes": "nz_engine_play, export, nz_replay_append of every position, per-game statistics dicts"}
     assert len(stats) == n_round and len(batch) == 2048
+    if in_flight < 2:
+        rb.close()
+        g.engine.close()
+        return out
+    # the same worker in the trainer's asynchronous mode: Gamer.play_forever with rounds in flight
+    done = []
+
+    def on_round(records, st):
+        done.append(len(st))
+        if len(done) >= 2 + 2 * rounds:                    # two rounds of warm-up (the second engine's first launches)
+            g.stop()
+
+    marks = []
+    import threading
+    t_async = threading.Thread(target=lambda: g.play_forever(rounds_in_flight=in_flight, on_round=lambda r, st: (on_round(r, st), marks.append(time.perf_counter()))))
+    t_async.start()
+    t_async.join()
+    if len(marks) >= 2 + 2 * rounds:
+        out["play_forever_in_flight"] = {"engines": in_flight, "value": 2 * rounds * n_round / (marks[1 + 2 * rounds] - marks[1]), "unit": "games/s",
+                                           "rounds": 2 * rounds}
     rb.close()
     g.engine.close()
     return out
@@ -415,7 +436,7 @@ def main():
                                   "at_workload_trees": dict(sel[args.games], trees=args.games)}
         eng.close()
         # ---- the reference-shaped surface and one SCS configuration, driver-timed
-        out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
+        out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank, in_flight=args.rounds_in_flight)
         out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
         if args.rounds_in_flight > 1:
             key = "rounds_in_flight_%d" % args.rounds_in_flight

@@ -335,7 +335,10 @@ class RoundPipeline:
         self.engines = [make_engine() for _ in range(depth)]
         self.device = self.engines[0].device
         with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream() for _ in self.engines]
+            # high priority: those streams have hardware queues of their own.  Normal-priority streams share four
+            # queues with the null stream, and the pair that lands on the null stream's queue loses the overlap
+            # (measured: 107 k instead of 116 k games/s for every second pipeline of a process).
+            self.streams = [torch.cuda.Stream(priority=-1) for _ in self.engines]
         self.pool = ThreadPoolExecutor(max_workers=depth)
         self.pending = []                 # (round index, engine, future), oldest first
         self.submitted = 0

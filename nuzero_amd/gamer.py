@@ -196,30 +196,38 @@ class Gamer:
         """One self-play round: `num_games` games.  Returns (records, stats list)."""
         if self.is_scs:
             return self._play_scs_games()
-        nm = self._network() if self.shared_storage is not None else None
-        if nm is not None and self._loaded != (id(nm), nm.sync()):
-            s = nm.spec()
-            self.engine.set_weights(nm.state_dict(), width=s.width, num_blocks=s.num_blocks, recall=s.recall,
-                                    value_activation=s.value_activation,
-                                    recurrent_iterations=self.recurrent_iterations, arch=s.arch,
-                                    kernel_size=s.kernel_size)
-            if self.cache_choice != "disabled":
-                self.engine.cache_all_positions()
-            self._loaded = (id(nm), nm.version)
+        self._loaded = self._load_weights(self.engine, self._loaded)
         self.engine.play(base_seed=self.base_seed, next_base_seed=self.base_seed + self.num_games)
         self.base_seed += self.num_games
+        return self._consume_round(self.engine)
+
+    def _load_weights(self, engine, loaded):
+        """The engine's weights follow the network in shared storage (Gamer.py:40,61); `loaded`: what it holds now."""
+        nm = self._network() if self.shared_storage is not None else None
+        if nm is None or loaded == (id(nm), nm.sync()):
+            return loaded
+        s = nm.spec()
+        engine.set_weights(nm.state_dict(), width=s.width, num_blocks=s.num_blocks, recall=s.recall,
+                           value_activation=s.value_activation, recurrent_iterations=self.recurrent_iterations,
+                           arch=s.arch, kernel_size=s.kernel_size)
+        if self.cache_choice != "disabled":
+            engine.cache_all_positions()
+        return (id(nm), nm.version)
+
+    def _consume_round(self, engine):
+        """A finished Tic-Tac-Toe round of `engine`: games to the replay buffer, records and statistics out."""
         on_device = hasattr(self.buffer, "save_games_from_engine")
         if on_device:
             # replay buffer in HBM: states, visit counts and outcomes go from the engine's export buffers into the
             # buffer's slots on the device (ReplayBuffer.save_game for every game of the round, in order)
-            ex = self.engine.export_device()
-            self.buffer.save_games_from_engine(self.engine, self.game_index, export=ex)
+            ex = engine.export_device()
+            self.buffer.save_games_from_engine(engine, self.game_index, export=ex)
             if not self.records:
                 r = {k: ex[k].cpu().numpy() for k in ("lengths", "tree_size", "n_children", "bias")}
                 return [], round_stats(r)
             r = {k: (v.cpu().numpy() if v is not None else None) for k, v in ex.items()}
         else:
-            r = self.engine.export(states=self.records)
+            r = engine.export(states=self.records)
         stats = round_stats(r)
         if not self.records:
             return [], stats
@@ -267,9 +275,51 @@ class Gamer:
             return stats[0], DeviceCacheStats(self.engine.cache_stats(), 0.8 if self.cache_choice == "keyless" else 0.7)
         return stats[0], DisabledCache(0.0 if self.cache_choice == "disabled" else 1.0)
 
-    def play_forever(self):
-        while not self.time_to_stop:
-            self.play_games()
+    def play_forever(self, rounds_in_flight=2, on_round=None):
+        """Gamer.play_forever (Gamer.py:99-101; the trainer's asynchronous mode, AlphaZero.py:404,496): rounds until
+        stop().  Tic-Tac-Toe rounds run `rounds_in_flight` at a time (RoundPipeline: the next round's workgroups take the
+        compute units the current round's tail leaves idle); every round is the one play_games() would play next, the
+        weights are looked up before each round starts, and finished rounds reach the replay buffer in order.
+        `on_round(records, stats)`: called after each round (tests, progress)."""
+        if self.is_scs or rounds_in_flight < 2:
+            while not self.time_to_stop:
+                out = self.play_games()
+                if on_round is not None:
+                    on_round(*out)
+            return
+        from .engine import RoundPipeline
+        first, made, loaded = self.engine, [], {}
+
+        def make():
+            if not made:
+                made.append(first)
+                return first
+            e = SelfPlayEngine(self.search_config, self.num_games, training=True, device=self.device, n_slots=first.n_slots)
+            made.append(e)
+            return e
+
+        pipe = RoundPipeline(make, depth=rounds_in_flight)
+        loaded[id(first)] = self._loaded
+        try:
+            while not self.time_to_stop or pipe.pending:
+                while len(pipe.pending) == rounds_in_flight or (self.time_to_stop and pipe.pending):
+                    _, eng = pipe.collect()
+                    out = self._consume_round(eng)
+                    if on_round is not None:
+                        on_round(*out)
+                if self.time_to_stop:
+                    break
+                eng = pipe.engines[pipe.submitted % rounds_in_flight]
+                loaded[id(eng)] = self._load_weights(eng, loaded.get(id(eng)))
+                pipe.submit(self.base_seed, next_base_seed=self.base_seed + rounds_in_flight * self.num_games)
+                self.base_seed += self.num_games
+        finally:
+            self._loaded = loaded.get(id(first))
+            while pipe.pending:
+                pipe.collect()
+            pipe.pool.shutdown()
+            for e in made[1:]:
+                e.close()
 
     def stop(self):
         self.time_to_stop = True

@@ -689,3 +689,49 @@ def test_round_pipeline_plays_the_same_rounds():
         assert got[i][1] == want[i][1], i
         for k in want[i][0]:
             assert np.array_equal(got[i][0][k], want[i][0][k]), (i, k)
+
+
+@pytest.mark.gpu
+def test_gamer_play_forever_keeps_two_rounds_in_flight():
+    """Gamer.play_forever (the trainer's asynchronous mode) with two rounds in flight: the rounds that reach the replay
+    buffer are, in order, the rounds play_games() plays one after the other -- same records, same statistics -- and the
+    weights of a round are those in shared storage when the round starts."""
+    import threading
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+
+    class tic_tac_toe:
+        pass
+
+    w = synthetic_recurrent_net_weights(5, 2, 1, 64, 2, True)
+    cfg = legacy_ttt_search_config(25)
+    N, SLOTS, ROUNDS = 48, 16, 5
+
+    def gamer():
+        return Gamer(ReplayBuffer(10 ** 6, 64), Network_Manager(w), tic_tac_toe, [], 0, cfg, 2, "disabled", num_games=N,
+                     concurrent_games=SLOTS, base_seed=300)
+
+    seq = gamer()
+    want = [seq.play_games() for _ in range(ROUNDS)]
+    free = gamer()
+    got = []
+
+    def on_round(records, stats):
+        got.append((records, stats))
+        if len(got) >= ROUNDS:
+            free.stop()
+
+    t = threading.Thread(target=free.play_forever, kwargs={"rounds_in_flight": 2, "on_round": on_round})
+    t.start()
+    t.join(timeout=120)
+    assert not t.is_alive() and len(got) >= ROUNDS
+    for (ra, sa), (rb, sb) in zip(want, got):
+        assert sa == sb
+        assert len(ra) == len(rb) == N
+        for a, b in zip(ra, rb):
+            assert a.length == b.length and a.terminal_value == b.terminal_value and a.child_policy == b.child_policy
+    assert free.buffer.len() == sum(r.length for recs, _ in got for r in recs)
+    assert free.base_seed == 300 + len(got) * N
