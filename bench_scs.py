@@ -139,7 +139,7 @@ def main():
             n_i.set_weights(w, args.iters)
             sets.append((ScsSelfPlay(cfg, search, per, device=local,
                                      nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None), n_i,
-                         torch.cuda.Stream(device=local)))
+                         torch.cuda.Stream(device=local, priority=-1)))
         results = [None] * S
 
         def run(i):

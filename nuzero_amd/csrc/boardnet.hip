@@ -792,6 +792,10 @@ __device__ __forceinline__ void fetch_weights16(const Fused16Op& op, u32x4 (&wre
     if (i < total) wreg[j] = *((gptr4u)op.w + i);
   }
 }
+__device__ __forceinline__ void fetch_weights16_chunk(const Fused16Op& op, u32x4 (&wreg)[FUSED16_WREGS], int tid, int j) {
+  const int i = tid + j * FUSED_THREADS;
+  if (i < op.ntiles * op.w_chunks) wreg[j] = *((gptr4u)op.w + i);
+}
 __device__ __forceinline__ void store_weights16(const Fused16Op& op, float* wbuf, const u32x4 (&wreg)[FUSED16_WREGS], int tid) {
   const int total = op.ntiles * op.w_chunks;
 #pragma unroll
@@ -811,11 +815,16 @@ __device__ __forceinline__ void step16(f32x4& acc, const u32x4 (&a)[3], const u3
 }
 // One (row tile, column tile) job as straight-line code: NTAPS x KGT steps.  `srow[tap]`: this lane's operand row of the
 // tap -- an off-board tap reads the buffer's row of zeros (row index = the workgroup's row count, never written).
+// `fetch`: this job also issues the loads of the NEXT layer's weights, one 16-byte chunk per thread every STEPS / 4
+// steps -- sixteen wavefronts issuing all four at the layer's start queue up at the texture addresser for 1.7 k cycles
+// before the first MFMA.
 template <int NTAPS, int KGT, bool WLDS>
 __device__ __forceinline__ void conv16_job(f32x4& acc, const float* __restrict__ lds, const int (&srow)[NTAPS], int off0,
                                            int cs0, int ps0, int kq, const float* __restrict__ wl,
-                                           const uint32_t* __restrict__ wg) {
+                                           const uint32_t* __restrict__ wg, bool fetch, const Fused16Op& next,
+                                           u32x4 (&wreg)[FUSED16_WREGS], int tid) {
   constexpr int STEPS = NTAPS * KGT;
+  static_assert(STEPS >= FUSED16_WREGS, "a chunk per STEPS / FUSED16_WREGS steps");
   constexpr int AHEAD = WLDS ? 0 : 3;         // weights read from L2: their loads run three steps ahead of the MFMAs
   u32x4 bq[AHEAD + 1][3];
   if constexpr (!WLDS) {
@@ -830,6 +839,10 @@ __device__ __forceinline__ void conv16_job(f32x4& acc, const float* __restrict__
 #pragma unroll
     for (int kg = 0; kg < KGT; ++kg) {
       const int st = tap * KGT + kg;
+      if constexpr (WLDS) {                     // (the layers that read weights from L2 have no registers to spare)
+        if (st % (STEPS / FUSED16_WREGS) == 0 && st / (STEPS / FUSED16_WREGS) < FUSED16_WREGS && fetch)
+          fetch_weights16_chunk(next, wreg, tid, st / (STEPS / FUSED16_WREGS));
+      }
       const int a0 = rbase + (((kg * 4 + kq) ^ sw) << 2);
       u32x4 a[3];
 #pragma unroll
@@ -926,21 +939,49 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 
   int rt_cached = -1, srow[ntaps];
   const int zrow_index = prog->zrow_index;              // every buffer's row of zeros
-  // a layer's descriptor is fetched two layers ahead (a chain of scalar loads from memory costs a microsecond when waited for)
+  // A layer's descriptor is fetched two layers ahead, and with VECTOR loads (lane i holds dword i; v_readlane makes
+  // the scalars a layer later): scalar loads come back out of order, so the first wait for an LDS read behind one waits
+  // for memory too -- a microsecond per layer.
   const int zero_at_op = prog->zero_at_op, n_zero = prog->n_zero, zero_len = prog->zero_len;
   const int wbuf_off0 = prog->wbuf_off[0], wbuf_off1 = prog->wbuf_off[1];
+  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
+  static_assert(sizeof(Fused16Op) % 4 == 0 && OP_DWORDS <= 64, "one dword per lane");
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
   Fused16Op d0 = n_ops > 0 ? prog->ops[0] : Fused16Op{}, d1 = n_ops > 1 ? prog->ops[1] : Fused16Op{};
+  uint32_t dvec = (n_ops > 2 && lane < OP_DWORDS) ? ops_words[2 * OP_DWORDS + lane] : 0u;
   for (int o = 0; o < n_ops; ++o) {
     const Fused16Op op = d0, next = d1;       // both read from memory at least a layer ago
     d0 = d1;
-    if (o + 2 < n_ops) d1 = prog->ops[o + 2];
+    if (o + 2 < n_ops) {
+      uint32_t words[OP_DWORDS];
+#pragma unroll
+      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
+      __builtin_memcpy(&d1, words, sizeof(Fused16Op));
+    }
+    if (o + 3 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 3) * OP_DWORDS + lane];
+#ifdef NZ_FUSED_STAMPS
+    asm volatile("" :: "s"(d1.off0), "s"(d1.kg0));
+    const unsigned long long t_top = __builtin_amdgcn_s_memtime();
+#endif
     if (o == zero_at_op) {                            // (the previous layer's barrier is behind us; the first reader is two layers on)
       for (int i = tid; i < n_zero * zero_len; i += FUSED_THREADS)
         lds[prog->zero_off[i / zero_len] + i % zero_len] = 0.f;
     }
     const bool next_lds = o + 1 < n_ops && next.w_lds;
     u32x4 wreg[FUSED16_WREGS];
-    if (next_lds) fetch_weights16(next, wreg, tid);
+    bool to_fetch = next_lds;                 // the wavefront's first job issues the loads (a wavefront without one: below)
+#ifdef NZ_ABL_F16_NOFETCH
+    to_fetch = false;
+#endif
+    if (to_fetch && !op.w_lds) {
+      fetch_weights16(next, wreg, tid);
+      to_fetch = false;
+    }
+#ifdef NZ_FUSED_STAMPS
+    const unsigned long long t_fetch = __builtin_amdgcn_s_memtime();
+    if (o == 3) { tk_args = t_top - ts; tk_clear = t_fetch - t_top; }
+#endif
     const int kgt = op.kg0 + op.kg1;
     const int n_jobs = row_tiles * op.ntiles;
     const float* wbuf = lds + (op.w_slot ? wbuf_off1 : wbuf_off0);
@@ -964,54 +1005,98 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
       const unsigned long long j0 = __builtin_amdgcn_s_memtime();
 #endif
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef NZ_ABL_F16_NOK
+      if (n_ops < 0)
+#endif
+      {
       const float* wl = wbuf + (size_t)ct * op.w_chunks * 4 + lane * 4;            // LDS copy of the column tile
       const uint32_t* wg = op.w + (size_t)ct * op.w_chunks * 4 + lane * 4;         // packed stream in L2
-      if (op.w_lds && kgt == 1) conv16_job<ntaps, 1, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
-      else if (op.w_lds && kgt == 2) conv16_job<ntaps, 2, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
-      else if (kgt == 1) conv16_job<ntaps, 1, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
-      else if (kgt == 2) conv16_job<ntaps, 2, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
-      else if (kgt == 3) conv16_job<ntaps, 3, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
-      else conv16_job<ntaps, 4, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg);
+      if (op.w_lds && kgt == 1) conv16_job<ntaps, 1, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      else if (op.w_lds && kgt == 2) conv16_job<ntaps, 2, true>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      else if (kgt == 1) conv16_job<ntaps, 1, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      else if (kgt == 2) conv16_job<ntaps, 2, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      else if (kgt == 3) conv16_job<ntaps, 3, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      else conv16_job<ntaps, 4, false>(acc, lds, srow, op.off0, op.cs0, op.ps0, kq, wl, wg, to_fetch, next, wreg, tid);
+      }
+      to_fetch = false;
 #ifdef NZ_FUSED_STAMPS
       asm volatile("" :: "v"(acc));
       if (o < 32) tk_k[o] += __builtin_amdgcn_s_memtime() - j0;
 #endif
+      // epilogue: the tile's four values per lane go through each step TOGETHER (one wave-uniform switch, then four
+      // independent chains the scheduler interleaves: expm1f / tanhf one value at a time is a chain of dependent
+      // instructions four times as long)
       const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
+      const int orow0 = rt * 16 + r4;
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int orow = rt * 16 + r4 + r;
-        if (orow < rows) {
-          float v = acc[r];
-          if (op.offr >= 0) {                               // the residual's pieces add up to the float32 it was split from
+      for (int r = 0; r < 4; ++r) v[r] = acc[r];
+      if (op.offr >= 0) {                                   // the residual's pieces add up to the float32 it was split from
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = orow0 + r;
+          if (orow < rows) {
             const uint16_t* rp = reinterpret_cast<const uint16_t*>(lds + op.offr + orow * op.csr +
                                                                    (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
-            v += (bf16_bits_to_float(rp[0]) + bf16_bits_to_float(rp[2 * op.psr])) + bf16_bits_to_float(rp[4 * op.psr]);
+            v[r] += (bf16_bits_to_float(rp[0]) + bf16_bits_to_float(rp[2 * op.psr])) + bf16_bits_to_float(rp[4 * op.psr]);
           }
-          v = activate(v, op.act);
-          if (op.psd == 0) {
-            lds[op.offd + orow * op.csd + col] = v;
-          } else {
-            uint16_t h3[3];
-            split3_bits(v, h3);
+        }
+      }
+#ifdef NZ_ABL_F16_NOACT
+      switch (0) {
+#else
+      switch (op.act) {
+#endif
+        case 1:
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+          break;
+        case 2:
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+          break;
+        case 3:
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : expm1f(v[r]);
+          break;
+        default: break;
+      }
+      if (op.psd == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (orow0 + r < rows) lds[op.offd + (orow0 + r) * op.csd + col] = v[r];
+      } else {
+        uint16_t h3[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) split3_bits(v[r], h3[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int orow = orow0 + r;
+          if (orow < rows) {
             uint16_t* dp = reinterpret_cast<uint16_t*>(lds + op.offd + orow * op.csd +
                                                        (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
-            dp[0] = h3[0];
-            dp[2 * op.psd] = h3[1];
-            dp[4 * op.psd] = h3[2];
+            dp[0] = h3[r][0];
+            dp[2 * op.psd] = h3[r][1];
+            dp[4 * op.psd] = h3[r][2];
           }
         }
       }
     }
+    if (to_fetch) fetch_weights16(next, wreg, tid);
 #ifdef NZ_FUSED_STAMPS
     if (o < 32) FSTAMP(tk_job[o]);
 #endif
     float* const next_wbuf = lds + (next.w_slot ? wbuf_off1 : wbuf_off0);
+#ifndef NZ_ABL_F16_NOFETCH
     if (next_lds && !next.w_after_barrier) store_weights16(next, next_wbuf, wreg, tid);
+#endif
     __syncthreads();
+#ifndef NZ_ABL_F16_NOFETCH
     if (next_lds && next.w_after_barrier) {
       store_weights16(next, next_wbuf, wreg, tid);
       __syncthreads();
     }
+#endif
 #ifdef NZ_FUSED_STAMPS
     if (o < 32) FSTAMP(tk_bar[o]);
 #endif

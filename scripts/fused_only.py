@@ -8,7 +8,7 @@ net = BoardNet("convnet", 86, 21, 5, 5, width=32, num_blocks=8, max_batch=1024)
 net.set_weights(synthetic_weights(0, convnet_param_shapes(86, 21, 3, 32, 8)))
 x = (torch.rand((1024, 86, 5, 5), device="cuda") < 0.15).float()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-for fused in (True, False):
+for fused in ((True,) if os.environ.get('FUSED_ONLY') else (True, False)):
     net.fused(fused)
     for n in (64, 256, 512, 640, 768, 1024):
         n_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
