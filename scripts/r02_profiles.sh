@@ -10,7 +10,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p
 cp $(ls /tmp/p_bench/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_f -- python3 $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_f.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_w -- python3 $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_w.log 2>&1 || exit 1
-python3 $R/scripts/pmc_traffic.py $(ls /tmp/p_f/*/*counter_collection.csv | head -1) $(ls /tmp/p_w/*/*counter_collection.csv | head -1) "selfplay_kernel<false>" $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline" $C 4096 16384 100 2 || exit 1
+python3 $R/scripts/pmc_traffic.py $(ls /tmp/p_f/*/*counter_collection.csv | head -1) $(ls /tmp/p_w/*/*counter_collection.csv | head -1) "selfplay_kernel<false>" $O/pmc_traffic.json "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline" $C 4096 65536 100 2 || exit 1
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/p_s1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-extras --no-cpu-baseline > $O/pmc_s1.log 2>&1 || exit 1
 python3 $R/scripts/pmc_summary.py $(ls /tmp/p_s1/*/*counter_collection.csv | head -1) "selfplay_kernel<false>" > $O/pmc_selfplay_kernel_sq.txt
 cat $O/pmc_selfplay_kernel_sq.txt
