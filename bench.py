@@ -2,13 +2,14 @@
 """Benchmark of the self-play hot path (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--games G] [--round R] [--sims S]
-    python bench.py --round 65536 --no-extras      # longer rounds on the same 4096 trees: less end-of-round tail
+    python bench.py --round 16384 --no-extras      # the round size `value` was measured on until round 2
 
 A "step" is one self-play round on one GPU: R Tic-Tac-Toe games played to the
 end on G concurrent game trees (slots that finish a game take the next one, as
 the reference's ActorPool does), S MCTS simulations per move, network fused
 into the search (BASELINE.json configs[1]: 100 sims/move, 4096 concurrent games,
-1 x MI355X; default R = 4 G), followed -- when N > 1 -- by the RCCL gather of the
+1 x MI355X; default R = 16 G: one launch of the persistent kernel, whose start and end-of-round
+tail are paid once per round), followed -- when N > 1 -- by the RCCL gather of the
 finished games to rank 0's replay buffer (and preceded, once, by the broadcast of
 the weights from rank 0).  Weights are synthetic (random-init RecurrentNet(2,1,64,2),
 seed 0); games need no dataset.  Prints ONE JSON line on rank 0.
@@ -29,9 +30,11 @@ Extra keys (N = 1)
   scs_config4       BASELINE.json configs[3]: SCS 5x5, ConvNet(32 filters x 8 layers, square convs), 200 sims/move,
                     1024 concurrent games, one whole round in the library (nz_scs_search_play)
   gamer_surface     Gamer.play_games with the replay buffer on the device: the whole reference-shaped round (search,
-                    save_game for every game, statistics), games/s; with --rounds-in-flight N the sub-key
-                    play_forever_in_flight: the same worker in the trainer's asynchronous mode (Gamer.play_forever)
-  rounds_in_flight_N  (only with --rounds-in-flight N) the same rounds with N engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
+                    save_game for every game, statistics), games/s
+  round_4x, gamer_surface_round_4x   (only with --rounds-in-flight N) rounds of 4 G games, the size `value` was measured
+                    on until round 2: the engine alone, and the Gamer surface with the sub-key play_forever_in_flight
+                    (the same worker in the trainer's asynchronous mode, Gamer.play_forever)
+  rounds_in_flight_N  (only with --rounds-in-flight N) rounds of 4 G games with N engines in flight (nuzero_amd.engine.RoundPipeline: two HIP streams, the
                     next round's workgroups take the compute units the current round's tail leaves idle), games/s --
                     the reference's asynchronous mode (Gamers that play_forever); NOT `value`, whose rounds run one
                     after the other so that the kernel's duration in `roofline` and in rocprofv3's stats is that of an
@@ -234,7 +237,7 @@ def main():
     ap.add_argument("--round", type=int, default=0,
                     help="games per self-play round (= per launch of the persistent kernel) per GPU; default 16 x --games: "
                          "a launch starts with every workgroup's first network pass and ends with workgroups that have run "
-                         "out of games, a fixed cost that rounds of 4 x --games (key `round_4x`, the default until round 2) "
+                         "out of games, a fixed cost that rounds of 4 x --games (key `round_4x` under --rounds-in-flight, the default until round 2) "
                          "pay four times as often")
     ap.add_argument("--sims", type=int, default=100)
     ap.add_argument("--iters", type=int, default=2, help="recurrent iterations")
@@ -440,22 +443,27 @@ def main():
                                   "launches": big["launches"], "simulations_per_s": big["simulations_per_s"],
                                   "at_workload_trees": dict(sel[args.games], trees=args.games)}
         eng.close()
-        # ---- the same engine with rounds of 4 x concurrent games (what `value` was measured on until round 2)
-        small = SelfPlayEngine(cfg, n_small, training=True, device=local_rank, n_slots=args.games)
-        small.set_weights(weights, recurrent_iterations=args.iters)
-        small.play(base_seed=3 * 10 ** 6, next_base_seed=3 * 10 ** 6 + n_small)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        for i in range(1, 4):
-            small.play(base_seed=3 * 10 ** 6 + i * n_small, next_base_seed=3 * 10 ** 6 + (i + 1) * n_small)
-        torch.cuda.synchronize()
-        out["round_4x"] = {"value": 3 * n_small / (time.perf_counter() - ts), "unit": "games/s", "rounds": 3,
-                           "games_per_round": n_small, "concurrent_games": args.games}
-        small.close()
         # ---- the reference-shaped surface and one SCS configuration, driver-timed
-        out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_small, local_rank, in_flight=args.rounds_in_flight)
-        out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["round_4x"]["value"]
+        out["gamer_surface"] = gamer_surface(cfg, weights, args.games, n_round, local_rank)
+        out["gamer_surface"]["vs_kernel_rate"] = out["gamer_surface"]["value"] / out["value"]
         if args.rounds_in_flight > 1:
+            # rounds of 4 x concurrent games (what `value` was measured on until round 2), one after the other and
+            # overlapped; behind the flag so that the default command launches the persistent kernel at ONE size and
+            # its rocprofv3 average stays comparable with roofline.avg_launch_us
+            small = SelfPlayEngine(cfg, n_small, training=True, device=local_rank, n_slots=args.games)
+            small.set_weights(weights, recurrent_iterations=args.iters)
+            small.play(base_seed=3 * 10 ** 6, next_base_seed=3 * 10 ** 6 + n_small)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for i in range(1, 4):
+                small.play(base_seed=3 * 10 ** 6 + i * n_small, next_base_seed=3 * 10 ** 6 + (i + 1) * n_small)
+            torch.cuda.synchronize()
+            out["round_4x"] = {"value": 3 * n_small / (time.perf_counter() - ts), "unit": "games/s", "rounds": 3,
+                               "games_per_round": n_small, "concurrent_games": args.games}
+            small.close()
+            gs = gamer_surface(cfg, weights, args.games, n_small, local_rank, in_flight=args.rounds_in_flight)
+            gs["vs_round_4x"] = gs["value"] / out["round_4x"]["value"]
+            out["gamer_surface_round_4x"] = gs
             key = "rounds_in_flight_%d" % args.rounds_in_flight
             out[key] = rounds_in_flight(cfg, weights, args.games, n_small, local_rank, args.iters, depth=args.rounds_in_flight)
             out[key]["vs_round_4x"] = out[key]["value"] / out["round_4x"]["value"]
