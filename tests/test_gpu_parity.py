@@ -315,6 +315,44 @@ def test_full_size_round_equals_c_oracle():
     eng.close()
 
 
+def test_bench_round_of_65536_games():
+    """The round bench.py times by default: 65,536 games on 4096 concurrent trees (16 games per tree in one launch of the
+    persistent kernel).  Size-independent invariants on every game; every eighth game replayed exactly by the C oracle
+    from the GPU network's own outputs (each game has its own random stream, so any subset can be replayed)."""
+    from nuzero_amd.weights import synthetic_recurrent_net_weights
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    from oracle import cref
+    cfg = legacy_ttt_search_config(100)
+    n_games, n_slots, base = 65536, 4096, 900001
+    eng = _engine(cfg, n_games, n_slots=n_slots)
+    eng.set_weights(synthetic_recurrent_net_weights(0, 2, 1, 64, 2, True))
+    table = _gpu_table(eng)
+    eng.play(base_seed=base)
+    r = eng.export(trace=True)
+    c = eng.counters()
+    assert eng.desync_count() == 0 and eng.live_games() == 0
+    L = r["lengths"]
+    assert L.min() >= 5 and L.max() <= 9
+    assert c["simulations"] == int(L.sum()) * 100
+    for m in range(9):
+        live = L > m
+        assert np.array_equal(r["visits"][live, m].sum(1), r["tree_size"][live, m] - 1)
+        legal = 9 - m                                             # a root's children are its legal moves
+        assert (r["n_children"][live, m] == legal).all()
+    assert (r["tree_size"][:, 0] == 100).all()
+    states = r["states"]
+    assert ((states == 0) | (states == 1)).all() and (states[:, 0] == 0).all()
+    stones = states.reshape(n_games, 9, -1).sum(2)
+    for m in range(9):
+        assert (stones[L > m, m] == m).all()
+    sample = np.arange(0, n_games, 8)
+    o = cref.play_games(table, cfg, [base + int(g) for g in sample])
+    for k in ("lengths", "outcomes", "actions", "visits", "tree_size", "n_children", "bias", "child_prior",
+              "child_value_sum", "root_value_sum"):
+        assert np.array_equal(r[k][sample], o[k]), k
+    eng.close()
+
+
 @pytest.mark.parametrize("width,iters,vact,sims,n_games,n_slots", [
     (16, 16, "tanh", 30, 40, 24),      # small net, 16 recurrent iterations, ragged tile
     (64, 1, "relu", 400, 20, 20),      # relu value head, 400 simulations (BASELINE configs[2] search depth)
