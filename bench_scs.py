@@ -50,6 +50,10 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="split the concurrent games into this many independent sets, each with its own engine, network "
                          "buffers, host thread and HIP stream (native evaluator, library loop): their small kernels overlap")
+    ap.add_argument("--cu-split", action="store_true",
+                    help="with --streams S: every set's stream gets its own 1/S of the compute units (hipExtStreamCreateWithCUMask), "
+                         "so that one set's network workgroups and another's rule waves do not share a CU; run with "
+                         "NZ_BOARDNET_CUS=<CUs per set> so that the one-launch network sizes its grid for the share")
     ap.add_argument("--config", default=os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
     args = ap.parse_args()
     import torch
@@ -133,13 +137,26 @@ def main():
         assert args.games % S == 0
         per = args.games // S
         sets = []
+
+        def masked_stream(i):
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            n_cu = torch.cuda.get_device_properties(local).multi_processor_count
+            words = (n_cu + 31) // 32
+            mask = (ctypes.c_uint32 * words)()
+            for cu in range(i * n_cu // S, (i + 1) * n_cu // S):
+                mask[cu // 32] |= 1 << (cu % 32)
+            st = ctypes.c_void_p()
+            err = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+            assert err == 0, "hipExtStreamCreateWithCUMask: %d" % err
+            return torch.cuda.ExternalStream(st.value, device=local)
         for i in range(S):
             n_i = BoardNet(args.arch, cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=args.filters,
                            num_blocks=args.layers, kernel_size=3, max_batch=per, device=local, hex=args.hex)
             n_i.set_weights(w, args.iters)
             sets.append((ScsSelfPlay(cfg, search, per, device=local,
                                      nodes_per_game=(1 + args.sims * args.nodes_per_sim) if args.nodes_per_sim else None), n_i,
-                         torch.cuda.Stream(device=local, priority=-1)))
+                         masked_stream(i) if args.cu_split else torch.cuda.Stream(device=local, priority=-1)))
         results = [None] * S
 
         def run(i):

@@ -1524,6 +1524,7 @@ void build_fused16(nz_boardnet* h) {
     if (!pc.dev16) return;
   int n_cu = 0;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess || n_cu <= 0) return;
+  if (const char* e = getenv("NZ_BOARDNET_CUS")) n_cu = std::max(1, std::min(n_cu, atoi(e)));   // a stream with a CU mask: its share of the chip
   // positions per workgroup: an even share of the largest batch over the CUs if that fits in LDS, else as many as fit (the
   // grid then has more workgroups than CUs: they take the CUs in turn)
   const int p_even = (h->max_batch + n_cu - 1) / n_cu;
