@@ -805,13 +805,16 @@ __device__ __forceinline__ void store_weights16(const Fused16Op& op, float* wbuf
   }
 }
 // one K step (32 channels of one tap): the six piece products, small terms first (net_dev.hpp pair_mfma)
+// The weights go in as the MFMA's first operand, so the output tile comes out transposed: lane l holds ROW l & 15 and the
+// four consecutive channels 4 (l >> 4) .. + 3 -- one address, one bounds check and three 8-byte stores per lane in the
+// epilogue where the other orientation (a column and four rows per lane) needs four of each and twelve 2-byte stores.
 __device__ __forceinline__ void step16(f32x4& acc, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
-  acc = wide_mfma(a[1], b[1], acc);
-  acc = wide_mfma(a[2], b[0], acc);
-  acc = wide_mfma(a[0], b[2], acc);
-  acc = wide_mfma(a[1], b[0], acc);
-  acc = wide_mfma(a[0], b[1], acc);
-  acc = wide_mfma(a[0], b[0], acc);
+  acc = wide_mfma(b[1], a[1], acc);
+  acc = wide_mfma(b[0], a[2], acc);
+  acc = wide_mfma(b[2], a[0], acc);
+  acc = wide_mfma(b[0], a[1], acc);
+  acc = wide_mfma(b[1], a[0], acc);
+  acc = wide_mfma(b[0], a[0], acc);
 }
 // One (row tile, column tile) job as straight-line code: NTAPS x KGT steps.  `srow[tap]`: this lane's operand row of the
 // tap -- an off-board tap reads the buffer's row of zeros (row index = the workgroup's row count, never written).
@@ -1026,62 +1029,55 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
       asm volatile("" :: "v"(acc));
       if (o < 32) tk_k[o] += __builtin_amdgcn_s_memtime() - j0;
 #endif
-      // epilogue: the tile's four values per lane go through each step TOGETHER (one wave-uniform switch, then four
-      // independent chains the scheduler interleaves: expm1f / tanhf one value at a time is a chain of dependent
-      // instructions four times as long)
-      const int col = ct * 16 + (lane & 15), r4 = (lane >> 4) * 4;
-      const int orow0 = rt * 16 + r4;
-      float v[4];
+      // epilogue: this lane's row, its four channels; the four values go through each step TOGETHER (one wave-uniform
+      // switch, then four independent chains the scheduler interleaves)
+      const int orow = rt * 16 + (lane & 15), c0 = ct * 16 + (lane >> 4) * 4;
+      if (orow < rows) {
+        const int chunk = (((c0 >> 3) ^ ((orow >> 2) & 3)) << 2) + ((c0 & 7) >> 1);     // float offset of the 8 bytes in the row
+        float v[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[r];
-      if (op.offr >= 0) {                                   // the residual's pieces add up to the float32 it was split from
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int orow = orow0 + r;
-          if (orow < rows) {
-            const uint16_t* rp = reinterpret_cast<const uint16_t*>(lds + op.offr + orow * op.csr +
-                                                                   (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
-            v[r] += (bf16_bits_to_float(rp[0]) + bf16_bits_to_float(rp[2 * op.psr])) + bf16_bits_to_float(rp[4 * op.psr]);
-          }
+        for (int r = 0; r < 4; ++r) v[r] = acc[r];
+        if (op.offr >= 0) {                                 // the residual's pieces add up to the float32 it was split from
+          const float* rp = lds + op.offr + orow * op.csr + chunk;
+          const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + op.psr),
+                      q2 = *reinterpret_cast<const uint2*>(rp + 2 * op.psr);
+          auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+          auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
+          v[0] += (lo(q0.x) + lo(q1.x)) + lo(q2.x);
+          v[1] += (hi(q0.x) + hi(q1.x)) + hi(q2.x);
+          v[2] += (lo(q0.y) + lo(q1.y)) + lo(q2.y);
+          v[3] += (hi(q0.y) + hi(q1.y)) + hi(q2.y);
         }
-      }
 #ifdef NZ_ABL_F16_NOACT
-      switch (0) {
+        switch (0) {
 #else
-      switch (op.act) {
+        switch (op.act) {
 #endif
-        case 1:
+          case 1:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-          break;
-        case 2:
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            break;
+          case 2:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
-          break;
-        case 3:
+            for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+            break;
+          case 3:
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : fast_expm1(v[r]);
-          break;
-        default: break;
-      }
-      if (op.psd == 0) {
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : fast_expm1(v[r]);
+            break;
+          default: break;
+        }
+        if (op.psd == 0) {                                  // float32 rows (logits, value plane): 16 bytes
+          *reinterpret_cast<f32x4*>(lds + op.offd + orow * op.csd + c0) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          uint16_t h3[4][3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (orow0 + r < rows) lds[op.offd + (orow0 + r) * op.csd + col] = v[r];
-      } else {
-        uint16_t h3[4][3];
+          for (int r = 0; r < 4; ++r) split3_bits(v[r], h3[r]);
+          float* dp = lds + op.offd + orow * op.csd + chunk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) split3_bits(v[r], h3[r]);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int orow = orow0 + r;
-          if (orow < rows) {
-            uint16_t* dp = reinterpret_cast<uint16_t*>(lds + op.offd + orow * op.csd +
-                                                       (((col >> 3) ^ ((orow >> 2) & 3)) << 2)) + (col & 7);
-            dp[0] = h3[r][0];
-            dp[2 * op.psd] = h3[r][1];
-            dp[4 * op.psd] = h3[r][2];
-          }
+          for (int piece = 0; piece < 3; ++piece)
+            *reinterpret_cast<uint2*>(dp + piece * op.psd) =
+                uint2{(uint32_t)h3[0][piece] | ((uint32_t)h3[1][piece] << 16), (uint32_t)h3[2][piece] | ((uint32_t)h3[3][piece] << 16)};
         }
       }
     }
