@@ -406,17 +406,34 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
   const int unit_base = 5 + 36, target_plane = unit_base + 2 * per_player, att_base = target_plane + 1,
             phase_base = att_base + S;
   // planes that are dense: written whole; every other plane is zero-filled first
-  for (int i = lane; i < r.channels * T; i += 64) {
-    const int c = ROWS ? i % r.channels : i / T, t = ROWS ? i / r.channels : i - (i / T) * T;
+  auto dense = [&](int c) {                      // the value of a plane that is the same on every tile (terrain: per tile)
     float v = 0.0f;
-    if (c < 3) v = r.terrain_f[t][c];
-    else if (c >= phase_base) {
+    if (c >= phase_base) {
       const int k = c - phase_base;
       if (k < 4) v = k == s.sub_phase ? 1.0f : 0.0f;
       else if (k == 4) v = (float)((double)s.turn / (double)r.turns);
       else v = s.player == 1 ? -1.0f : 1.0f;
     }
-    at(c, t) = v;
+    return v;
+  };
+  if constexpr (ROWS) {
+    // a tile's channels are contiguous: lane = channel (and channel + 64), tile by tile -- no division per element
+    const int c0 = lane, c1 = lane + 64;
+    const float v0 = dense(c0), v1 = dense(c1);
+    for (int t = 0; t < T; ++t) {
+      float* row = img + (size_t)t * 16 * stride;
+      if (c0 < r.channels) row[c0] = c0 < 3 ? r.terrain_f[t][c0] : v0;
+      if (c1 < r.channels) row[c1] = v1;
+    }
+    for (int c = lane + 128; c < r.channels; c += 64) {        // (more than 128 planes: none of the shipped games)
+      const float v = dense(c);
+      for (int t = 0; t < T; ++t) img[(size_t)t * 16 * stride + c] = v;
+    }
+  } else {
+    for (int i = lane; i < r.channels * T; i += 64) {
+      const int c = i / T, t = i - c * T;
+      at(c, t) = c < 3 ? r.terrain_f[t][c] : dense(c);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
   for (int p = 0; p < 2; ++p)
