@@ -149,17 +149,22 @@ __device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, c
   };
   for (int b = 0; b < p.pw_blocks; ++b) {
     const int hi = p.pw_hi[b], be = p.pw_be[b];
-    float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f, r4 = 0.f, r5 = 0.f, r6 = 0.f, r7 = 0.f;
+    // numpy's eight running sums r[0..7] of the block live in lanes 0..7 (one compare and one add per entry instead of
+    // eight of each); adding 0.0f to the other seven is exact
+    float racc = 0.f;
+    const int lane8 = (int)(threadIdx.x & 63);
     while (i < k) {
       const int ix = entry_idx(i);
       if (ix >= be) break;
       const float v = entry_val(i);
-      const int j = (ix - lo) & 7;                     // adding 0.0f to the other seven is exact
-      r0 += j == 0 ? v : 0.f; r1 += j == 1 ? v : 0.f; r2 += j == 2 ? v : 0.f; r3 += j == 3 ? v : 0.f;
-      r4 += j == 4 ? v : 0.f; r5 += j == 5 ? v : 0.f; r6 += j == 6 ? v : 0.f; r7 += j == 7 ? v : 0.f;
+      racc += lane8 == ((ix - lo) & 7) ? v : 0.f;
       ++i;
     }
-    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), read from lane 0
+    const float t1 = racc + __shfl_xor(racc, 1, 64);
+    const float t2 = t1 + __shfl_xor(t1, 2, 64);
+    const float t3 = t2 + __shfl_xor(t2, 4, 64);
+    float res = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t3)));
     while (i < k) {
       if (entry_idx(i) >= hi) break;
       res = res + entry_val(i);
