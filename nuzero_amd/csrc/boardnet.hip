@@ -890,12 +890,24 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // The program's header and its first two layer descriptors come in three VECTOR loads issued together (lane i holds
+  // dword i, v_readlane makes the scalars): as scalar loads they are a chain of dependent round trips to memory, a
+  // few microseconds at the start of every launch.
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4), OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
+  static_assert(HDR_DWORDS <= 64 && sizeof(Fused16Op) % 4 == 0 && OP_DWORDS <= 64, "one dword per lane");
+  const gptr1u prog_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog);
+  const uint32_t hdr_v = lane < HDR_DWORDS ? prog_words[lane] : 0u;
+  const uint32_t op0_v = lane < OP_DWORDS ? prog_words[HDR_DWORDS + lane] : 0u;
+  const uint32_t op1_v = lane < OP_DWORDS ? prog_words[HDR_DWORDS + OP_DWORDS + lane] : 0u;
+#define HDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int n_pos = n_dev ? *n_dev : n_host;
   const int P = (n_pos + (int)gridDim.x - 1) / (int)gridDim.x;
   const int p0 = blockIdx.x * P;
   if (p0 >= n_pos) return;                                  // uniform per workgroup
   const int np = min(P, n_pos - p0);
-  const int hw = prog->hw, H = prog->h, Wd = prog->wd, n_ops = prog->n_ops;
+  const int hw = HDR(hw), H = HDR(h), Wd = HDR(wd), n_ops = HDR(n_ops);
+  const int h_in_off = HDR(in_off), h_in_cs = HDR(in_cs), h_in_ps = HDR(in_ps), zrow_index = HDR(zrow_index);   // (every buffer's row of zeros)
   const int rows = np * hw, row_tiles = (rows + 15) >> 4;
   constexpr int ntaps = HEX ? 7 : 9;
   const int kq = lane >> 4;
@@ -909,15 +921,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 #endif
   // K groups reach past a narrow layer's channels and row tiles past the last row (zero weights, discarded rows): what
   // they read must be numbers, so everything starts as zeros
-  for (int i = prog->clear_from + tid * 4; i < prog->lds_floats; i += FUSED_THREADS * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < 3 * prog->in_cs; i += FUSED_THREADS)     // the input's row of zeros
-    lds[prog->in_off + (i / prog->in_cs) * prog->in_ps + prog->zrow_index * prog->in_cs + i % prog->in_cs] = 0.f;
+  for (int i = HDR(clear_from) + tid * 4, end = HDR(lds_floats); i < end; i += FUSED_THREADS * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < 3 * h_in_cs; i += FUSED_THREADS)     // the input's row of zeros
+    lds[h_in_off + (i / h_in_cs) * h_in_ps + zrow_index * h_in_cs + i % h_in_cs] = 0.f;
   __syncthreads();
 #ifdef NZ_FUSED_STAMPS
   unsigned long long tk_clear = 0; FSTAMP(tk_clear);
 #endif
   {   // this workgroup's input rows, split into pieces (global row of (position n, cell c): ((n >> 4) * hw + c) * 16 + (n & 15))
-    const int cs = prog->in_cs, ps = prog->in_ps;
+    const int cs = h_in_cs, ps = h_in_ps;
     const int chunks = in_channels >> 3;                    // eight channels = one 16-byte chunk of a piece
     for (int i = tid; i < rows * chunks; i += FUSED_THREADS) {
       const int r = i / chunks, c8 = i - r * chunks;
@@ -926,7 +938,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
       const float* src = in_rows + grow * in_channels + c8 * 8;
       u32x4 q0, q1, q2;
       wide_split8(*reinterpret_cast<const f32x4*>(src), *reinterpret_cast<const f32x4*>(src + 4), q0, q1, q2);
-      float* d = lds + prog->in_off + r * cs + ((c8 ^ ((r >> 2) & 3)) << 2);
+      float* d = lds + h_in_off + r * cs + ((c8 ^ ((r >> 2) & 3)) << 2);
       *reinterpret_cast<u32x4*>(d) = q0;
       *reinterpret_cast<u32x4*>(d + ps) = q1;
       *reinterpret_cast<u32x4*>(d + 2 * ps) = q2;
@@ -935,26 +947,31 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 #ifdef NZ_FUSED_STAMPS
   unsigned long long tk_split = 0; FSTAMP(tk_split);
 #endif
-  if (n_ops > 0 && prog->ops[0].w_lds) {
+  const int wbuf_off0 = HDR(wbuf_off[0]), wbuf_off1 = HDR(wbuf_off[1]);
+  Fused16Op d0, d1;
+  {
+    uint32_t words[OP_DWORDS];
+#pragma unroll
+    for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(op0_v, i);
+    __builtin_memcpy(&d0, words, sizeof(Fused16Op));
+#pragma unroll
+    for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(op1_v, i);
+    __builtin_memcpy(&d1, words, sizeof(Fused16Op));
+  }
+  if (n_ops > 0 && d0.w_lds) {
     u32x4 wreg[FUSED16_WREGS];
-    fetch_weights16(prog->ops[0], wreg, tid);
-    store_weights16(prog->ops[0], lds + prog->wbuf_off[prog->ops[0].w_slot], wreg, tid);
+    fetch_weights16(d0, wreg, tid);
+    store_weights16(d0, lds + (d0.w_slot ? wbuf_off1 : wbuf_off0), wreg, tid);
   }
   __syncthreads();
   FSTAMP(tk_in);
 
   int rt_cached = -1, srow[ntaps];
-  const int zrow_index = prog->zrow_index;              // every buffer's row of zeros
   // A layer's descriptor is fetched two layers ahead, and with VECTOR loads (lane i holds dword i; v_readlane makes
   // the scalars a layer later): scalar loads come back out of order, so the first wait for an LDS read behind one waits
   // for memory too -- a microsecond per layer.
-  const int zero_at_op = prog->zero_at_op, n_zero = prog->n_zero, zero_len = prog->zero_len;
-  const int wbuf_off0 = prog->wbuf_off[0], wbuf_off1 = prog->wbuf_off[1];
-  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
-  static_assert(sizeof(Fused16Op) % 4 == 0 && OP_DWORDS <= 64, "one dword per lane");
-  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  const int zero_at_op = HDR(zero_at_op), n_zero = HDR(n_zero), zero_len = HDR(zero_len);
   const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
-  Fused16Op d0 = n_ops > 0 ? prog->ops[0] : Fused16Op{}, d1 = n_ops > 1 ? prog->ops[1] : Fused16Op{};
   uint32_t dvec = (n_ops > 2 && lane < OP_DWORDS) ? ops_words[2 * OP_DWORDS + lane] : 0u;
   for (int o = 0; o < n_ops; ++o) {
     const Fused16Op op = d0, next = d1;       // both read from memory at least a layer ago
@@ -1102,11 +1119,11 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
   }
 
   // softmax over ALL logits and value = tanh(mean): exactly fused_net_kernel's tail (the two outputs are float32 rows)
-  float* pol = lds + prog->pol_off;
-  const int pp = prog->pol_cs;
-  const float* val = lds + prog->val_off;
-  const int vp = prog->val_cs;
-  const int A = prog->planes * hw;
+  float* pol = lds + HDR(pol_off);
+  const int pp = HDR(pol_cs);
+  const float* val = lds + HDR(val_off);
+  const int vp = HDR(val_cs);
+  const int A = HDR(planes) * hw;
   const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
   for (int pl = wave; pl < np; pl += FUSED_WAVES) {
     const size_t n = (size_t)(p0 + pl);
