@@ -825,6 +825,8 @@ struct nz_scs_search {
   int32_t *leaf_game = nullptr, *nchild = nullptr, *status = nullptr;
   double *noise = nullptr, *uniforms = nullptr;
   int64_t waves = 0;
+  int32_t* active_pinned = nullptr;          // pinned host word + event: the early-finish poll of the move loop
+  hipEvent_t ev_poll = nullptr;
   // nz_scs_search_play_round: the round's store and the slot bookkeeping of one move
   RoundStore round{};
   int64_t round_capacity = 0, round_games = 0;
@@ -1012,6 +1014,8 @@ void nz_scs_search_destroy(nz_scs_search* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* q : h->allocs) (void)hipFree(q);
+  if (h->active_pinned) (void)hipHostFree(h->active_pinned);
+  if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
   {
     const RoundStore& r = h->round;
     void* store[] = {r.action, r.tree_size, r.children, r.child_action, r.child_visit, r.status, r.bias, r.root_value_sum,
@@ -1288,6 +1292,11 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     const int sims = h->cfg.mcts_simulations;
+    bool poll_pending = false;
+    if (!h->active_pinned) {
+      S_HIP(h, hipHostMalloc((void**)&h->active_pinned, sizeof(int32_t), hipHostMallocDefault));
+      S_HIP(h, hipEventCreateWithFlags(&h->ev_poll, hipEventDisableTiming));
+    }
     for (int w = 0;; ++w) {
       // two (leaf, active) counter pairs: wave w counts into pair w & 1 and zeroes the other one for wave w + 1
       h->p.leaf_count = counters + 3 * (w & 1);
@@ -1298,18 +1307,32 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
       h->p.c_hit_base = G * (1 + (w & 1));
       hipLaunchKernelGGL(wave_kernel, dim3(G), dim3(64), 0, s, h->p, w ? 3 : 2, h->probs, h->value, net_rows, h->leaf_game);
       ++h->waves;
-      if ((w & 7) == 7 || w >= sims - 1) {
+      if (w >= sims - 1) {                       // the move's last waves: wait for the count of games still searching
         int32_t active = 0;
         S_HIP(h, hipMemcpyAsync(&active, h->p.active_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         S_HIP(h, hipStreamSynchronize(s));
         if (active == 0) break;
         if (w > sims + 2) return sfail(h, NZ_ERR_STATE, "internal: a move's searches did not finish in %d waves", w);
+      } else if ((w & 7) == 7) {
+        // every game may have finished early (simulations that end in terminal leaves do not wait for a wave): the count
+        // is copied to pinned memory and looked at eight waves later -- no wait, the GPU is never left without work; the
+        // waves launched in between find nothing to do
+        if (poll_pending && hipEventQuery(h->ev_poll) == hipSuccess) {
+          poll_pending = false;
+          if (*h->active_pinned == 0) break;
+        }
+        if (!poll_pending) {
+          S_HIP(h, hipMemcpyAsync(h->active_pinned, h->p.active_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+          S_HIP(h, hipEventRecord(h->ev_poll, s));
+          poll_pending = true;
+        }
       }
       if (nz_boardnet_forward_rows(net, G, h->p.leaf_count, nullptr, h->probs, h->value, stream) != NZ_OK)
         return sfail(h, NZ_ERR_HIP, "network: %s", nz_boardnet_last_error(net));
       if (h->cache_bits > 0)                   // the leaves the network just evaluated enter the table (KeylessCache.put)
         hipLaunchKernelGGL(cache_put_kernel, dim3(G), dim3(64), 0, s, h->p, h->p.leaf_count);
     }
+    if (poll_pending) S_HIP(h, hipEventSynchronize(h->ev_poll));     // (long done: the move's last waves were waited for)
     st = nz_scs_search_end_move(h, h->uniforms, stream);
     if (st != NZ_OK) return st;
   }
