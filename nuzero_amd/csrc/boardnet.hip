@@ -924,7 +924,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
   for (int i = HDR(clear_from) + tid * 4, end = HDR(lds_floats); i < end; i += FUSED_THREADS * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int i = tid; i < 3 * h_in_cs; i += FUSED_THREADS)     // the input's row of zeros
     lds[h_in_off + (i / h_in_cs) * h_in_ps + zrow_index * h_in_cs + i % h_in_cs] = 0.f;
-  __syncthreads();
+  // (no barrier here: the input rows written next are none of the floats cleared above; the barrier after them covers both)
 #ifdef NZ_FUSED_STAMPS
   unsigned long long tk_clear = 0; FSTAMP(tk_clear);
 #endif
