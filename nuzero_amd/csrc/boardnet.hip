@@ -1118,45 +1118,65 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused1
 #endif
   }
 
-  // softmax over ALL logits and value = tanh(mean): exactly fused_net_kernel's tail (the two outputs are float32 rows)
+  // softmax over ALL logits and value = tanh(mean) (the two outputs are float32 rows).  A workgroup has few positions and
+  // sixteen wavefronts: WPP wavefronts share a position's logits; their partial maxima and sums meet in LDS (the first
+  // floats of weight buffer 1, which nothing reads after the last layer's barrier).
   float* pol = lds + HDR(pol_off);
   const int pp = HDR(pol_cs);
   const float* val = lds + HDR(val_off);
   const int vp = HDR(val_cs);
   const int A = HDR(planes) * hw;
-  const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
-  for (int pl = wave; pl < np; pl += FUSED_WAVES) {
+  const int WPP = np <= 4 ? 4 : (np <= 8 ? 2 : 1), groups = FUSED_WAVES / WPP;
+  const int group = wave / WPP, sub = wave - group * WPP, step = 64 * WPP;
+  const int i0 = sub * 64 + lane;
+  const int cell0 = i0 % hw, plane0 = i0 / hw, dcell = step % hw, dplane = step / hw;
+  float* red = lds + h_in_off;                             // [2][FUSED_WAVES]
+  for (int base = 0; base < np; base += groups) {           // (the same trip count for every wavefront: barriers inside)
+    const int pl = base + group;
+    const bool on = pl < np;
     const size_t n = (size_t)(p0 + pl);
     float* prow = pol + pl * hw * pp;
     float mx = -INFINITY;
-    for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
-      const float v = prow[cell * pp + plane];
-      if (logits) logits[n * A + i] = v;
-      mx = fmaxf(mx, v);
-      cell += dcell; plane += dplane;
-      if (cell >= hw) { cell -= hw; ++plane; }
-    }
+    if (on)
+      for (int i = i0, cell = cell0, plane = plane0; i < A; i += step) {
+        const float v = prow[cell * pp + plane];
+        if (logits) logits[n * A + i] = v;
+        mx = fmaxf(mx, v);
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
+      }
+    if (!probs) continue;                                   // (uniform)
     for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w));
-    if (probs) {
-      float sum = 0.f;
-      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    for (int j = 0; j < WPP; ++j) mx = fmaxf(mx, red[group * WPP + j]);
+    float sum = 0.f;
+    if (on)
+      for (int i = i0, cell = cell0, plane = plane0; i < A; i += step) {
         const float e = expf(prow[cell * pp + plane] - mx);
         prow[cell * pp + plane] = e;
         sum += e;
         cell += dcell; plane += dplane;
         if (cell >= hw) { cell -= hw; ++plane; }
       }
-      for (int w = 32; w; w >>= 1) sum += __shfl_xor(sum, w);
-      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+    for (int w = 32; w; w >>= 1) sum += __shfl_xor(sum, w);
+    if (lane == 0) red[FUSED_WAVES + wave] = sum;
+    __syncthreads();
+    sum = 0.f;
+    for (int j = 0; j < WPP; ++j) sum += red[FUSED_WAVES + group * WPP + j];
+    if (on)
+      for (int i = i0, cell = cell0, plane = plane0; i < A; i += step) {
         probs[n * A + i] = prow[cell * pp + plane] / sum;
         cell += dcell; plane += dplane;
         if (cell >= hw) { cell -= hw; ++plane; }
       }
-    }
+    if (base + groups < np) __syncthreads();                // `red` is written again
+  }
+  for (int pl = wave; pl < np; pl += FUSED_WAVES) {
     float sv = 0.f;
     for (int c = lane; c < hw; c += 64) sv += val[(pl * hw + c) * vp];
     for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w);
-    if (lane == 0) value[n] = tanhf(sv / (float)hw);
+    if (lane == 0) value[(size_t)(p0 + pl)] = tanhf(sv / (float)hw);
   }
 #ifdef NZ_FUSED_STAMPS
   FSTAMP(tk_fin);
