@@ -488,8 +488,6 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     if (lane == 0) {
       p.pending[g] = -1;
       p.sims_left[g] = sims_in - 1;
-      atomicAdd((unsigned long long*)&p.counters[0], 1ull);
-      atomicAdd((unsigned long long*)&p.counters[1], 1ull);
     }
     // backup (Explorer.py:132-135): the path's statistics were read above; the leaf's new children do not touch them
     if (lane < plen) {
@@ -504,9 +502,19 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
   NZ_STAMP(0);                                  // expansion + backup of the evaluated leaf
-  if (!(mode & 2) || (pend >= 0 && !expanding)) return;
+  // The run's simulation / expansion counters take ONE atomic each per game and wave, as the wavefront leaves: a thousand
+  // games add to the same two words, and an atomic still on its way holds up every later wait for a load (vmcnt counts
+  // in order) -- the descent's first node reads stood behind the expansion's.
+  const unsigned long long n_expanded = expanding ? 1ull : 0ull;
+  auto leave = [&](unsigned long long sims_done) {
+    if (lane == 0) {
+      if (sims_done) atomicAdd((unsigned long long*)&p.counters[0], sims_done);
+      if (n_expanded) atomicAdd((unsigned long long*)&p.counters[1], n_expanded);
+    }
+  };
+  if (!(mode & 2) || (pend >= 0 && !expanding)) { leave(n_expanded); return; }
   int sims_left = expanding ? sims_in - 1 : sims_in;
-  if (sims_left <= 0) return;
+  if (sims_left <= 0) { leave(n_expanded); return; }
 
   {   // rules -> LDS: 16 bytes per lane and load, all loads in flight before the first store
     static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
@@ -669,9 +677,9 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 #endif
   if (lane == 0) {
     p.sims_left[g] = sims_left;
-    if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)n_sim);
     if (queued || sims_left > 0) atomicAdd(p.active_count, 1);
   }
+  leave((unsigned long long)n_sim + n_expanded);
 }
 
 __global__ void search_status_kernel(SearchParams p, int32_t* out) {
