@@ -100,6 +100,18 @@ def cpu_baseline(sims, seconds=15.0, max_procs=64):
                       f"(python oracle + torch fp32 net, 1 thread each)"}
 
 
+def launch_ranks(n):
+    """One process per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port), started from a process
+    that has made no GPU call; stdout (rank 0's JSON line) passes through.  Returns the launcher's exit code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def git_commit():
     try:
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
@@ -252,11 +264,15 @@ def main():
     n_round = args.round if args.round > 0 else 16 * args.games
     n_small = 4 * args.games                  # the round size of `round_4x`, `gamer_surface` and `rounds_in_flight_N`
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: this process starts the N ranks itself (one process per GPU) BEFORE it
+        # makes any GPU call, relays rank 0's JSON line and exits with the launcher's code; it never touches a GPU
+        raise SystemExit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus disagree")
 
     # the CPU baseline runs first, in worker processes, before this process touches the GPU
     cpu = None
@@ -269,6 +285,9 @@ def main():
     from nuzero_amd.search_config import legacy_ttt_search_config
     from nuzero_amd import dist as nzdist
 
+    visible = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if visible < world or local_rank >= visible:
+        raise SystemExit(f"{world} GPUs requested, {visible} visible on this node (rank {rank}, local rank {local_rank})")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as td
@@ -280,7 +299,15 @@ def main():
     weights = nzdist.broadcast_weights(weights, src=0, device=torch.device("cuda", local_rank)) if world > 1 else weights
     eng = SelfPlayEngine(cfg, n_round, training=True, device=local_rank, n_slots=args.games)
     eng.set_weights(weights, recurrent_iterations=args.iters)
-    gather = nzdist.ReplayGather(eng, world, rank) if world > 1 else None
+    # rank 0 owns the shared replay buffer (in its HBM): every round's games of every rank reach it through one RCCL
+    # gather + one append (ReplayBuffer.save_game for each gathered game, rank-major)
+    gather = shared = None
+    if world > 1:
+        if rank == 0:
+            from nuzero_amd.replay_device import DeviceReplayBuffer
+            shared = DeviceReplayBuffer(window_size=2 * world * n_round, batch_size=2048, state_shape=(2, 3, 3),
+                                        num_actions=9, max_game_length=9, device=local_rank)
+        gather = nzdist.ReplayGather(eng, world, rank, buffer=shared)
 
     def barrier():
         if world > 1:
@@ -333,6 +360,9 @@ def main():
         "expansions_per_s": exp_total / dt, "simulations_per_s": sims_total / dt,
         "commit": git_commit(),
     }
+    if gather is not None and rank == 0:
+        out["replay_gather"] = {"ranks_seen": gather.ranks_seen, "games_saved": gather.games_saved,
+                                "buffer_positions": shared.len(), "buffer_games": shared.played_games()}
 
     if not args.no_extras and world == 1:
         flops_pos = eng.net_flops_per_position()

@@ -389,3 +389,88 @@ def test_broadcast_weights_single_process():
     w = synthetic_recurrent_net_weights(3, 2, 1, 16, 2, True)
     got = nzdist.broadcast_weights(w)
     assert list(got) == list(w) and all(np.array_equal(got[k].numpy(), w[k]) for k in w)
+
+
+class _FakeEngine:
+    def __init__(self, payload):
+        self.payload = payload
+
+    def export_device(self):
+        return self.payload
+
+
+class _IndexBuffer:
+    """Host stand-in for DeviceReplayBuffer.save_games_from_engine (the order logic is the real ReplayIndex)."""
+
+    def __init__(self):
+        from nuzero_amd.replay_device import ReplayIndex
+        self.index, self.tags = ReplayIndex(window_size=100), []
+
+    def save_games_from_engine(self, engine, game_index, export=None):
+        self.index.save_games(export["lengths"].numpy(), game_index)
+        self.tags += export["states"][:, 0, 0, 0, 0].tolist()
+
+
+def _replay_gather_worker(rank, world, port, ret):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as td
+    from nuzero_amd import dist as nzdist
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G, T = 5, 9
+        buf = _IndexBuffer() if rank == 0 else None
+        total = 0
+        for rnd in range(2):
+            p = _payload(rank, G, T)
+            p["lengths"] = torch.full((G,), 5 + rank + rnd, dtype=torch.int32)
+            p["states"][:, :, 0, 0, 0] = float(100 * rnd + 10 * rank)
+            if rnd == 0:
+                rg = nzdist.ReplayGather(_FakeEngine(p), world, rank, buffer=buf, game_index=3)
+            rg.engine = _FakeEngine(p)
+            out = rg.gather()
+            total += G * (5 + rnd) + G * (6 + rnd)
+            if rank == 0:
+                assert rg.ranks_seen == world and rg.games_saved == (rnd + 1) * world * G
+                assert len(buf.index) == total
+            else:
+                assert out is None and rg.ranks_seen == 0
+        if rank == 0:
+            ret["ok"] = buf.tags == [0.0] * G + [10.0] * G + [100.0] * G + [110.0] * G
+        else:
+            ret["ok1"] = True
+    finally:
+        td.destroy_process_group()
+
+
+def test_replay_gather_fills_the_buffer_on_two_ranks_gloo():
+    """ReplayGather with a buffer: every round's gathered games reach rank 0's replay buffer, rank-major, and the gather
+    reports how many ranks it saw (the N > 1 product path of bench.py)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_replay_gather_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret.get("ok") is True and ret.get("ok1") is True
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no WORLD_SIZE): the parent starts the two ranks itself before touching a GPU;
+    on a node with fewer GPUs each rank says so and the command exits non-zero -- not with a 'use a launcher' message."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node has the GPUs: the command would run the benchmark")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "2 GPUs requested" in r.stderr and "launch with torch.distributed.run" not in r.stderr
