@@ -222,9 +222,13 @@ nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* e
                              void* stream);
 /* As above plus the select work done: out[0] simulations, out[1] expansions,
  * out[2] internal nodes whose children were scored (descent levels), out[3]
- * children scored, out[4] nodes created by expansions.  Used to price the tree
- * phase's algorithmic bytes. */
-nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out5_host, void* stream);
+ * children scored.  Writes exactly FOUR values. */
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream);
+/* The first n_out (1..5) of: the four above, then out[4] nodes created by
+ * expansions.  Used to price the tree phase's algorithmic bytes (SURVEY.md
+ * section 8d).  The caller states its array's length, so later additions never
+ * write past an older caller's array. */
+nz_status nz_engine_counters_n(nz_engine* e, int64_t* out_host, int32_t n_out, void* stream);
 
 /* Algorithmic FLOPs of one network evaluation (one position): sum over convs of
  * 2 * C_out * C_in * 49, i.e. only the taps that fall inside the 3x3 board. */
@@ -483,7 +487,9 @@ nz_status nz_replay_check(nz_replay* h, void* stream);
  * policy_loss: cross entropy with label smoothing 0.02 (AlphaZero.py:327), KL divergence, masked MSE
  * (Utils/Functions/loss_functions.py:7-26); value_loss: squared / absolute error (loss_functions.py:28-33);
  * normalize_policy: divide the policy loss by log(batch) as the reference does (AlphaZero.py:912-915).
- * workspace_dev: 2 * batch floats.  float32 arithmetic; results agree with the reference's to ~1e-6 relative. */
+ * workspace_dev: 2 * batch floats.  float32 arithmetic; results agree with the reference's to ~1e-6 relative.
+ * Masked MSE with a target row of zeros only (the reference raises ZeroDivisionError there): losses3[1] and [2] come out
+ * NaN, that sample's dlogits row is zeros. */
 enum { NZ_LOSS_CE = 0, NZ_LOSS_KLD = 1, NZ_LOSS_MSE = 2 };
 enum { NZ_LOSS_SE = 0, NZ_LOSS_AE = 1 };
 nz_status nz_loss_forward_backward(const float* logits_dev, const float* values_dev, const float* target_policies_dev,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nz_engine_export_trace": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_engine_counters": (c_int32, [c_void_p, POINTER(c_int64), POINTER(c_int64), c_void_p]),
     "nz_engine_counters_ex": (c_int32, [c_void_p, POINTER(c_int64), c_void_p]),
+    "nz_engine_counters_n": (c_int32, [c_void_p, POINTER(c_int64), c_int32, c_void_p]),
     "nz_engine_net_flops": (c_int32, [c_void_p, POINTER(c_double)]),
     "nz_engine_net_matrix_flops": (c_int32, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "nz_net_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

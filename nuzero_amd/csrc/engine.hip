@@ -968,20 +968,25 @@ nz_status nz_engine_counters(nz_engine* e, int64_t* simulations_host, int64_t* e
   return NZ_OK;
 }
 
-nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out5_host, void* stream) {
-  int64_t* const out4_host = out5_host;
-  if (!e || !out4_host) return NZ_ERR_ARG;
+// n_out values of {simulations, expansions, scored nodes, scored children, nodes created}; the caller says how many its
+// array holds, so a caller built against an older header (four values) is never written past
+nz_status nz_engine_counters_n(nz_engine* e, int64_t* out_host, int32_t n_out, void* stream) {
+  if (!e || !out_host || n_out < 1 || n_out > 5) return NZ_ERR_ARG;
   hipStream_t s = as_stream(stream);
   const int32_t* src[5] = {e->tp.sim_count, e->tp.exp_count, e->tp.sel_nodes, e->tp.sel_children, e->tp.new_nodes};
   std::vector<int32_t> h(e->n_games);
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < n_out; ++i) {
     NZ_HIP(e, hipMemcpyAsync(h.data(), src[i], h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     NZ_HIP(e, hipStreamSynchronize(s));
     int64_t sum = 0;
     for (int32_t v : h) sum += v;
-    out4_host[i] = sum;
+    out_host[i] = sum;
   }
   return NZ_OK;
+}
+
+nz_status nz_engine_counters_ex(nz_engine* e, int64_t* out4_host, void* stream) {   // the first four, as first published
+  return nz_engine_counters_n(e, out4_host, 4, stream);
 }
 
 nz_status nz_engine_net_flops(const nz_engine* e, double* flops_host) {

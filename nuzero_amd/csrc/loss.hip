@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       const float k = s / (float)A;
       for (int i = tid; i < A; i += 256) g[i] = k * (expf(x[i] - lse) * aux - t[i]);
     } else {
-      const float k = 2.0f * s / cnt;
+      // (no target entry at all: the loss is 0 / 0 -- the reference raises ZeroDivisionError, loss_functions.py:7-26; the
+      // sample's policy term is NaN, so the batch's loss says so, but its gradient row is zeros: one bad sample does
+      // not poison the other samples' gradients)
+      const float k = cnt > 0.f ? 2.0f * s / cnt : 0.f;
       for (int i = tid; i < A; i += 256) {         // d/dx_i sum_j m_j (t_j - p_j)^2 = 2 p_i (sum_j m_j (t_j - p_j) p_j - m_i (t_i - p_i))
         const float p = expf(x[i] - lse);
         const float mi = t[i] != 0.f ? (t[i] - p) : 0.f;

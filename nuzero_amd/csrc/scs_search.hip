@@ -947,7 +947,7 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.cap = nodes_per_game & ~1;
   p.half_cap = p.cap / 2;
   p.tab_len = cfg->mcts_simulations * MAX_MOVES + 2;
-  p.max_path = MAX_MOVES + 8;                 // one tree level per game decision
+  p.max_path = std::max(MAX_MOVES + 8, 64);   // one tree level per game decision (at least a lane each: wave_kernel reads path[lane])
   {   // numpy's pairwise_sum over num_actions float32 entries (np.sum in Explorer.py:169) as a block program
     const int A = h->host_rules.planes * h->host_rules.tiles;
     p.num_actions = A;

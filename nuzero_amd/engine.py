@@ -292,7 +292,7 @@ class SelfPlayEngine:
     def counters(self):
         out = (c_int64 * 5)()
         with torch.cuda.device(self.device):
-            check(lib.nz_engine_counters_ex(self._h, out, _stream()), self._h)
+            check(lib.nz_engine_counters_n(self._h, out, 5, _stream()), self._h)
         return {"simulations": out[0], "expansions": out[1], "select_nodes": out[2], "select_children": out[3],
                 "new_nodes": out[4]}
 

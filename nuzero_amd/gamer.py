@@ -158,6 +158,11 @@ class Gamer:
         # records=False: play_games returns no per-game record objects (a round of 16 k games is 115 k Python lists);
         # with a device replay buffer (`buffer.save_games_from_engine`) the positions then never visit the host
         self.records = records
+        if not records and buffer is not None and not hasattr(buffer, "save_scs_games" if self.is_scs else "save_games_from_engine"):
+            # a host ReplayBuffer is filled from the record objects (buffer.save_game): without them every game of every
+            # round would be dropped and training would run on an empty buffer
+            raise ValueError("records=False needs a replay buffer that takes the games on the device "
+                             "(nuzero_amd.replay_device.DeviceReplayBuffer) or buffer=None")
         self._loaded = None
         self._wrapped = None
         if self.is_scs:

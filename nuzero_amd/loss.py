@@ -28,6 +28,9 @@ class _FusedLoss(torch.autograd.Function):
         tp = target_policies.reshape(B, -1).float().contiguous()
         tv = target_values.reshape(B).float().contiguous()
         assert tp.shape == x.shape
+        if policy_loss == POLICY_LOSSES["MSE"] and not bool((tp != 0).any(dim=1).all()):
+            # loss_functions.py:7-26 divides by the number of non-zero target entries of the sample
+            raise ZeroDivisionError("masked MSE policy loss: a sample's target policy is all zeros")
         losses = torch.empty(3, dtype=torch.float32, device=x.device)
         dlogits = torch.empty_like(x)
         dvalues = torch.empty_like(v)

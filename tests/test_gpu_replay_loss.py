@@ -243,3 +243,40 @@ def test_fused_loss_rejects_what_the_reference_cannot_compute():
         calculate_loss((x, v), torch.full((1, 9), 1 / 9.0, device="cuda"), torch.zeros(1, device="cuda"), "CEL", "SE", True)
     with pytest.raises(KeyError):
         calculate_loss((x, v), x, v, "nope", "SE")
+
+
+def test_masked_mse_with_an_all_zero_target_row():
+    """loss_functions.py:7-26 divides by the count of non-zero target entries: the surface raises ZeroDivisionError as
+    the reference does; at the C ABI the loss comes out NaN and the sample's gradient row is zeros, the other samples'
+    gradients untouched."""
+    import torch
+    from ctypes import c_void_p
+    from nuzero_amd import _lib
+    from nuzero_amd._lib import lib
+    from nuzero_amd.loss import calculate_loss
+    B, A = 3, 9
+    g = torch.Generator().manual_seed(5)
+    x, v = torch.randn((B, A), generator=g).cuda(), torch.randn(B, generator=g).cuda()
+    t = torch.softmax(torch.randn((B, A), generator=g), 1).cuda()
+    tv = torch.tensor([1.0, 0.0, -1.0]).cuda()
+    t_bad = t.clone()
+    t_bad[1] = 0
+    with pytest.raises(ZeroDivisionError):
+        calculate_loss((x, v), t_bad, tv, "MSE", "SE")
+
+    def raw(tp):
+        losses, dl, dv = torch.empty(3, device="cuda"), torch.empty_like(x), torch.empty_like(v)
+        work = torch.empty(2 * B, device="cuda")
+        st = lib.nz_loss_forward_backward(c_void_p(x.data_ptr()), c_void_p(v.data_ptr()), c_void_p(tp.data_ptr()),
+                                          c_void_p(tv.data_ptr()), B, A, _lib.NZ_LOSS_MSE, _lib.NZ_LOSS_SE, 0,
+                                          c_void_p(losses.data_ptr()), c_void_p(dl.data_ptr()), c_void_p(dv.data_ptr()),
+                                          c_void_p(work.data_ptr()), c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert st == _lib.NZ_OK
+        torch.cuda.synchronize()
+        return losses, dl
+
+    good_l, good_dl = raw(t)
+    bad_l, bad_dl = raw(t_bad)
+    assert torch.isnan(bad_l[1]) and torch.isnan(bad_l[2]) and not torch.isnan(bad_l[0])
+    assert torch.equal(bad_dl[1], torch.zeros(A, device="cuda"))
+    assert torch.equal(bad_dl[0], good_dl[0]) and torch.equal(bad_dl[2], good_dl[2]) and torch.isfinite(bad_dl).all()

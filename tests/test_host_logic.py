@@ -474,3 +474,20 @@ def test_bench_gpus_2_starts_its_own_ranks():
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "2 GPUs requested" in r.stderr and "launch with torch.distributed.run" not in r.stderr
+
+
+def test_gamer_without_records_refuses_a_host_replay_buffer():
+    """records=False with a buffer that is filled from record objects would drop every game silently."""
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    from nuzero_amd.search_config import legacy_ttt_search_config
+
+    class tic_tac_toe:
+        pass
+
+    class SCS_Game:
+        pass
+
+    for game, args in ((tic_tac_toe, []), (SCS_Game, ["x.yml"])):
+        with pytest.raises(ValueError, match="records=False"):
+            Gamer(ReplayBuffer(10, 4), None, game, args, 0, legacy_ttt_search_config(25), 2, num_games=4, records=False)
