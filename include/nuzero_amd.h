@@ -437,8 +437,23 @@ nz_status nz_scs_search_cache_stats(nz_scs_search* h, int64_t* out4_host);
  * SCS_Game.py:395-484): decisions per game (= the M of nz_scs_search_export's [G, M] / [G, M, C] arrays) and children
  * per node (= C, a multiple of 64, at most 256; a description that allows more is rejected by nz_scs_search_create). */
 nz_status nz_scs_search_limits(const nz_scs_search* h, int32_t* max_moves, int32_t* max_children);
-/* simulation waves (kernel rounds) the last nz_scs_search_play took */
+/* simulation waves (kernel rounds) the last nz_scs_search_play took (persistent route: one launch per move) */
 nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves);
+/* The persistent route of nz_scs_search_play / _play_moves / _play_round: one wavefront per game runs the whole
+ * search of a move -- descent, rules, the network for its own leaf, expansion, backup (Explorer.run_mcts,
+ * Search/Explorer.py:40-67, with one simulation in flight per tree, :49-61) -- in ONE launch per move, no game waiting
+ * for another.  Available for ConvNet / ResNet board nets on boards of up to 32 cells whose layers are at most 64
+ * channels wide, with the inference cache off; other configurations keep the wave-by-wave route.
+ * enable: 1 require it (a play fails where it is not available), 0 never, -1 the default (use it where available).
+ * *used (may be NULL): whether the last play ran on it. */
+nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* used);
+/* Test hook of the persistent route: keep the leaf evaluations of n games (games_host: indices), up to `capacity`
+ * each, in the order the game's search consumed them; n = 0 stops.  nz_scs_search_record_read (host pointers, any of the
+ * three arrays may be NULL): *count evaluations consumed, digests uint64 [.][2] (a 128-bit mix of the leaf's float32
+ * planes), probs float32 [.][A] post-softmax, values float32 [.]; rows = min(*count, capacity). */
+nz_status nz_scs_search_record(nz_scs_search* h, const int32_t* games_host, int32_t n, int32_t capacity);
+nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* count, uint64_t* digests_host,
+                                    float* probs_host, float* values_host);
 
 /* ---- host random streams (numpy legacy RandomState, MT19937) --------------
  * Replaces the reference's use of the global np.random stream

@@ -132,6 +132,9 @@ SIGNATURES = {
     "nz_scs_search_cache": (c_int32, [c_void_p, c_int64]),
     "nz_scs_search_cache_stats": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_scs_search_limits": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
+    "nz_scs_search_persistent": (c_int32, [c_void_p, c_int32, POINTER(c_int32)]),
+    "nz_scs_search_record": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
+    "nz_scs_search_record_read": (c_int32, [c_void_p, c_int32, POINTER(c_int32), c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_phase_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_replay_create": (c_int32, [POINTER(c_void_p), c_int64, c_int32, c_int32, c_int32]),
     "nz_replay_destroy": (None, [c_void_p]),

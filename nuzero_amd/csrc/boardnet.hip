@@ -38,10 +38,13 @@
 #include <vector>
 
 #include "../../include/nuzero_amd.h"
+#include "fused16_dev.hpp"
+#include "boardnet_internal.h"
+
+using namespace nz;
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   const float* src0;     // [rows][c0] NHWC, c0 a multiple of 16
@@ -212,36 +215,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 // positions x 64 channels = 32 accumulator tiles and issues 192 MFMAs per step from 36 LDS fragment reads.
 // Weights are the MFMA's A operand, so a lane ends up with four consecutive channels of one position:
 // the epilogue is one 16-byte store (and residual load) per accumulator tile.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int WIDE_GROUPS = 16;          // position groups (of 16) per workgroup tile
 constexpr int WIDE_NT = 8;               // 16-channel column tiles per workgroup tile
-
-__device__ __forceinline__ uint32_t wide_pack_hi16(float x0, float x1) {
-  return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x1), __builtin_bit_cast(uint32_t, x0), 0x07060302u);
-}
-__device__ __forceinline__ float wide_trunc(float x) {
-  return __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, x) & 0xFFFF0000u);
-}
-// 8 float32 -> three bf16 pieces (exact: 8 + 8 + 8 significant bits)
-__device__ __forceinline__ void wide_split8(const f32x4& lo, const f32x4& hi, u32x4& p0, u32x4& p1, u32x4& p2) {
-  const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  uint32_t a[4], b[4], c[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float x0 = v[2 * j], x1 = v[2 * j + 1];
-    a[j] = wide_pack_hi16(x0, x1);
-    const float r0 = x0 - wide_trunc(x0), r1 = x1 - wide_trunc(x1);
-    b[j] = wide_pack_hi16(r0, r1);
-    c[j] = wide_pack_hi16(r0 - wide_trunc(r0), r1 - wide_trunc(r1));
-  }
-  p0 = u32x4{a[0], a[1], a[2], a[3]};
-  p1 = u32x4{b[0], b[1], b[2], b[3]};
-  p2 = u32x4{c[0], c[1], c[2], c[3]};
-}
-__device__ __forceinline__ f32x4 wide_mfma(const u32x4& w, const u32x4& x, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
-}
 
 template <bool HEX>
 __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
@@ -471,7 +446,6 @@ __global__ __launch_bounds__(64) void finalize_kernel(const float* __restrict__ 
 //     per layer; the weight stream comes from L2 (every workgroup reads the same ~0.5 MB);
 //   * the softmax over all logits and the value's mean + tanh (finalize_kernel) run at the end, one wavefront per
 //     position, from LDS.
-constexpr int FUSED_MAX_OPS = 176;
 constexpr int FUSED_BUFFERS = 8;
 constexpr int FUSED_WAVES = 16;             // wavefronts per workgroup: a layer's jobs run side by side, four per SIMD
 constexpr int FUSED_THREADS = FUSED_WAVES * 64;
@@ -761,26 +735,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void fused_net_kernel(const FusedPro
 // in LDS as pieces, [piece][row][channel] bf16, split ONCE by the layer that makes them; a row's 16-byte chunks (eight
 // channels) are stored at chunk ^ ((row >> 2) & 3), so that the sixteen rows of a tile -- 64-byte rows for 32 channels --
 // spread over all banks without padding.  The logits and the value plane stay float32 rows for the softmax.
-struct Fused16Op {
-  const uint32_t* w;                       // [col tile][tap][32-channel group][piece][lane][4 dwords = 8 bf16]
-  int32_t off0, cs0, ps0, kg0;             // source 0: float offset, floats per row and per piece, piece stride, K groups
-  int32_t off1, cs1, ps1, kg1;             // source 1 (off1 = -1: none)
-  int32_t offd, csd, psd;                  // destination (psd = 0: float32 rows [row][csd])
-  int32_t offr, csr, psr;                  // residual (offr = -1: none)
-  int32_t ntiles, act;
-  int32_t w_lds, w_chunks;                 // 1: weights staged in LDS; 16-byte chunks of one column tile
-  int32_t w_slot, w_after_barrier;
-  int32_t pad;
-};
-struct Fused16Program {
-  int32_t n_ops, hw, h, wd, planes, hex;
-  int32_t zrow_index, lds_floats;           // every pieces buffer has a row of zeros at this index (never written)
-  int32_t clear_from, pad2;                 // LDS floats [clear_from, lds_floats) start as zeros: the activation buffers
-  int32_t wbuf_off[2];
-  int32_t in_off, in_cs, in_ps, pol_off, pol_cs, val_off, val_cs, pad;
-  int32_t zero_at_op, n_zero, zero_off[6], zero_len;   // rows of zeros to (re)make before that layer: buffers that take over a weight buffer's space
-  Fused16Op ops[FUSED_MAX_OPS];
-};
 constexpr int FUSED16_WREGS = 4;           // 16-byte chunks of the next layer's weights a thread carries (64 KB per layer)
 typedef const __attribute__((address_space(1))) u32x4* gptr4u;
 
@@ -803,18 +757,6 @@ __device__ __forceinline__ void store_weights16(const Fused16Op& op, float* wbuf
     const int i = tid + j * FUSED_THREADS;
     if (i < total) *reinterpret_cast<u32x4*>(wbuf + (size_t)i * 4) = wreg[j];
   }
-}
-// one K step (32 channels of one tap): the six piece products, small terms first (net_dev.hpp pair_mfma)
-// The weights go in as the MFMA's first operand, so the output tile comes out transposed: lane l holds ROW l & 15 and the
-// four consecutive channels 4 (l >> 4) .. + 3 -- one address, one bounds check and three 8-byte stores per lane in the
-// epilogue where the other orientation (a column and four rows per lane) needs four of each and twelve 2-byte stores.
-__device__ __forceinline__ void step16(f32x4& acc, const u32x4 (&a)[3], const u32x4 (&b)[3]) {
-  acc = wide_mfma(b[1], a[1], acc);
-  acc = wide_mfma(b[0], a[2], acc);
-  acc = wide_mfma(b[2], a[0], acc);
-  acc = wide_mfma(b[0], a[1], acc);
-  acc = wide_mfma(b[1], a[0], acc);
-  acc = wide_mfma(b[0], a[0], acc);
 }
 // One (row tile, column tile) job as straight-line code: NTAPS x KGT steps.  `srow[tap]`: this lane's operand row of the
 // tap -- an off-board tap reads the buffer's row of zeros (row index = the workgroup's row count, never written).
@@ -866,21 +808,6 @@ __device__ __forceinline__ void conv16_job(f32x4& acc, const float* __restrict__
     }
   }
 }
-// exp(x) - 1 for x <= 0 to an absolute error of ~1e-7 (v_exp_f32; libm's expm1f keeps the RELATIVE error small near zero,
-// thirty instructions the activations' 1e-5 tolerance has no use for)
-__device__ __forceinline__ float fast_expm1(float x) { return __expf(x) - 1.0f; }
-// exact three-way split of one value; piece i as the bf16 bit pattern
-__device__ __forceinline__ void split3_bits(float v, uint16_t (&h)[3]) {
-  float r = v;
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const uint32_t bits = __builtin_bit_cast(uint32_t, r) & 0xFFFF0000u;
-    h[i] = (uint16_t)(bits >> 16);
-    r = r - __builtin_bit_cast(float, bits);
-  }
-}
-__device__ __forceinline__ float bf16_bits_to_float(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
-
 template <bool HEX>
 __global__ __launch_bounds__(FUSED_THREADS) void fused16_net_kernel(const Fused16Program* __restrict__ prog,
                                                                     const float* __restrict__ in_rows, int in_channels,
@@ -1222,6 +1149,10 @@ struct nz_boardnet {
   int fused_grid = 0;
   size_t fused_lds_bytes = 0;
   Fused16Program* fused16_dev = nullptr;    // the same on the BF16 matrix cores (ConvNet), preferred when built
+  Fused16Program* wave_dev = nullptr;       // one position per wavefront (boardnet_wave_program), built on first request
+  nz::WaveNet wave{};
+  int wave_state = 0;                       // 0 not tried, 1 built, -1 not possible (wave_why)
+  std::string wave_why;
   int fused16_grid = 0;
   size_t fused16_lds_bytes = 0;
   std::string error;
@@ -1782,6 +1713,101 @@ bool build_fused16_resnet(nz_boardnet* h, int p_max) {
 }
 }  // namespace
 
+// The layer program for ONE wavefront evaluating ONE position (the persistent SCS self-play kernel): activations as
+// bf16 pieces in the wavefront's own LDS block, every layer's weights streamed from the packed L2 stream, no barriers.
+// Block, in floats: [input pieces -- once the first layer is done: the logits' and the value plane's float32 rows]
+// [trunk buffers 1, 2, 3]; the head layers' hidden buffers are the two trunk buffers that are free by then
+// (build_fused16_resnet's arrangement).  The leaf's float32 planes are staged over the trunk buffers before they are
+// split into the input pieces.
+bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* why) {
+  auto no = [&](const char* msg) { h->wave_state = -1; h->wave_why = msg; if (why) *why = msg; return false; };
+  if (!h || !h->ready) { if (why) *why = "no weights set"; return false; }
+  if (h->wave_state == 1) { *out = h->wave; return true; }
+  if (h->wave_state == -1) { if (why) *why = h->wave_why; return false; }
+  const nz_net_desc& nd = h->net;
+  if (nd.arch != NZ_ARCH_CONVNET && nd.arch != NZ_ARCH_RESNET) return no("only feed-forward nets (ConvNet, ResNet) have a per-wavefront form");
+  const int n_ops = (int)h->ops.size(), n_trunk = n_ops - 6;
+  if (n_trunk < 1 || n_ops > FUSED_MAX_OPS) return no("too many layers");
+  if (h->hw > 32) return no("boards of more than 32 cells do not fit two row tiles");
+  if (h->inp % 8 != 0 || h->inp > 128) return no("input planes");
+  for (const PackedConv& pc : h->convs)
+    if (!pc.dev16 || pc.coutp > 64 || pc.kg0_32 > 4) return no("a layer is wider than 64 channels");
+  const int rows = h->hw, R1 = rows + 1;
+  auto cs_of = [](int channels) { return (channels + 31) / 32 * 16; };
+  auto pieces_floats = [&](int channels) { return (size_t)3 * R1 * cs_of(channels); };
+  const int W = nd.width;
+  if (h->buffer_channels[4] > h->widthp || h->buffer_channels[6] > h->widthp) return no("head layers wider than the trunk");
+  Fused16Program pg;
+  memset(&pg, 0, sizeof(pg));
+  const int pol_cs = pad16(nd.policy_channels) + FUSED_PAD, val_cs = pad16(1) + FUSED_PAD;
+  const size_t pol_floats = ((size_t)rows * pol_cs + 3) / 4 * 4, val_floats = ((size_t)rows * val_cs + 3) / 4 * 4;
+  size_t off = 0;
+  const int off_i = 0;
+  off += std::max(pieces_floats(h->inp), pol_floats + val_floats);
+  const size_t act = pieces_floats(W);
+  const int off_t = (int)off;
+  const size_t stage = (size_t)rows * h->inp;
+  off += std::max(3 * act, (stage + 3) / 4 * 4);
+  if (off * sizeof(float) > 38 * 1024) return no("the activations of one position do not fit a wavefront's share of LDS");
+  pg.lds_floats = (int32_t)off;
+  pg.zrow_index = rows;
+  pg.n_ops = n_ops;
+  pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
+  pg.planes = nd.policy_channels; pg.hex = nd.hex ? 1 : 0;
+  pg.in_off = off_i; pg.in_cs = cs_of(h->inp); pg.in_ps = R1 * pg.in_cs;
+  pg.pol_off = off_i; pg.pol_cs = pol_cs;
+  pg.val_off = off_i + (int)pol_floats; pg.val_cs = val_cs;
+  const int cs_w = cs_of(W), ps_w = R1 * cs_w;
+  struct Place { int off, cs, ps; };
+  const Place in_pl{off_i, pg.in_cs, pg.in_ps};
+  const Place trunk[4] = {in_pl, {off_t, cs_w, ps_w}, {off_t + (int)act, cs_w, ps_w}, {off_t + 2 * (int)act, cs_w, ps_w}};
+  const int t_out = h->ops[n_trunk].src0;
+  if (t_out < 1 || t_out > 3) return no("internal: trunk output buffer");
+  int free_ids[2], nf = 0;
+  for (int b = 1; b <= 3; ++b)
+    if (b != t_out) free_ids[nf++] = b;
+  const Place pol_pl{pg.pol_off, pol_cs, 0}, val_pl{pg.val_off, val_cs, 0};
+  auto place_of = [&](int id, bool last_value) -> Place {
+    if (id >= 0 && id <= 3) return trunk[id];
+    if (id == 4) return trunk[free_ids[0]];
+    if (id == 5) return pol_pl;
+    if (last_value) return val_pl;
+    return trunk[free_ids[id == 6 ? 0 : 1]];
+  };
+  const int ntaps = nd.hex ? 7 : 9;
+  for (int i = 0; i < n_ops; ++i) {
+    const ConvOp& op = h->ops[i];
+    const PackedConv& pc = h->convs[i];
+    Fused16Op& f = pg.ops[i];
+    if (op.src1 >= 0) return no("a layer with two sources");
+    if (i > 0 && (op.src0 == 0 || op.res == 0)) return no("the input is read after the first layer");
+    const Place src = place_of(op.src0, false), dst = place_of(op.dst, i == n_ops - 1);
+    f.w = pc.dev16;
+    f.off0 = src.off; f.cs0 = src.cs; f.ps0 = src.ps; f.kg0 = pc.kg0_32;
+    f.off1 = -1; f.cs1 = 0; f.ps1 = 0; f.kg1 = 0;
+    f.offd = dst.off; f.csd = dst.cs; f.psd = dst.ps;
+    if (op.res >= 0) { const Place r = place_of(op.res, false); f.offr = r.off; f.csr = r.cs; f.psr = r.ps; }
+    else { f.offr = -1; f.csr = 0; f.psr = 0; }
+    f.ntiles = pc.coutp / 16; f.act = op.act;
+    f.w_chunks = ntaps * pc.kg0_32 * 3 * 64;
+    f.w_lds = 0; f.w_slot = 0; f.w_after_barrier = 0;
+    if (f.kg0 * 16 > f.cs0) return no("internal: K groups beyond the source rows");
+    if (dst.ps != 0 && f.ntiles * 8 > dst.cs) return no("internal: output tiles beyond the destination rows");
+  }
+  Fused16Program* dev = nullptr;
+  if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return no("device allocation failed");
+  if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return no("upload failed"); }
+  h->wave_dev = dev;
+  nz::WaveNet& w = h->wave;
+  w.prog = dev; w.lds_floats = pg.lds_floats; w.stage_off = off_t; w.stage_floats = (int32_t)((stage + 3) / 4 * 4);
+  w.inp = h->inp; w.in_channels = nd.in_channels;
+  w.hw = h->hw; w.rows = h->rows; w.cols = h->cols; w.planes = nd.policy_channels; w.hex = nd.hex ? 1 : 0; w.n_ops = n_ops;
+  w.flops = h->flops;
+  h->wave_state = 1;
+  *out = w;
+  return true;
+}
+
 extern "C" {
 
 const char* nz_boardnet_last_error(const nz_boardnet* h) { return h ? h->error.c_str() : g_err.c_str(); }
@@ -1794,6 +1820,7 @@ void nz_boardnet_destroy(nz_boardnet* h) {
   for (auto& c : h->convs) { (void)hipFree(c.dev); if (c.dev_split) (void)hipFree(c.dev_split); if (c.dev16) (void)hipFree(c.dev16); }
   if (h->fused_dev) (void)hipFree(h->fused_dev);
   if (h->fused16_dev) (void)hipFree(h->fused16_dev);
+  if (h->wave_dev) (void)hipFree(h->wave_dev);
   delete h;
 }
 
@@ -1846,6 +1873,8 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
   h->convs.clear(); h->ops.clear(); h->flops = 0; h->ready = false;
   if (h->fused_dev) { (void)hipFree(h->fused_dev); h->fused_dev = nullptr; }
   if (h->fused16_dev) { (void)hipFree(h->fused16_dev); h->fused16_dev = nullptr; }
+  if (h->wave_dev) { (void)hipFree(h->wave_dev); h->wave_dev = nullptr; }
+  h->wave_state = 0;
   const nz_net_desc& nd = h->net;
   const int W = nd.width, Wp = h->widthp, IN = nd.in_channels, INp = h->inp;
   const int vact = nd.value_activation == NZ_ACT_RELU ? 1 : 2;

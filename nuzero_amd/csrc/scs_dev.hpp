@@ -344,11 +344,24 @@ struct Scs {
 // Same results as Scs::for_each_legal / Scs::state_image, spread over the lanes: lane u owns
 // unit u (SCS_MAX_UNITS <= 64), lanes stride over tiles.  All 64 lanes must call these together.
 
+// The lanes of the wavefront meet: ONEWAVE = the workgroup is this one wavefront (__syncthreads is then no more than
+// that); otherwise the workgroup holds several independent wavefronts (the persistent self-play kernel: one game each)
+// and only this wavefront's own LDS accesses are ordered -- they issue in order, so a compiler fence is all it takes.
+template <bool ONEWAVE>
+__device__ __forceinline__ void scs_sync() {
+  if constexpr (ONEWAVE) {
+    __syncthreads();
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // mask: MASK words in LDS, zeroed here; bit a set <=> action a is legal.
-template <int WORDS>
+template <int WORDS, bool ONEWAVE = true>
 __device__ __forceinline__ void scs_legal_mask_wave(const ScsRules& r, const ScsState& s, uint32_t* mask, int lane) {
   for (int i = lane; i < WORDS; i += 64) mask[i] = 0u;
-  __syncthreads();
+  scs_sync<ONEWAVE>();
   auto f = [&](int a) { atomicOr(&mask[a >> 5], 1u << (a & 31)); };
   const Scs game(r, const_cast<ScsState&>(s));
   const int p = s.player, S = r.stacking, T = r.tiles;
@@ -388,7 +401,7 @@ __device__ __forceinline__ void scs_legal_mask_wave(const ScsRules& r, const Scs
       }
     if (lane == 0 && s.n_attackers > 0) f(r.attackers_limit * T + s.target);
   }
-  __syncthreads();
+  scs_sync<ONEWAVE>();
 }
 
 // img: [channels][tiles] float32 in global memory, fully written.
@@ -475,6 +488,7 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
 // Scs::step by a whole wavefront: lane 0 applies the action (a handful of stores), the turn
 // machine's "is any unit of player p queued / available / moved" scans (update_game_env,
 // :687-831) become one ballot each instead of a loop over the units.
+template <bool ONEWAVE = true>
 __device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, int action, int lane) {
   Scs game(r, s);
   const int T = r.tiles, S = r.stacking;
@@ -516,7 +530,7 @@ __device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, in
     }
   }
   if (lane == 0) ++s.length;
-  __syncthreads();
+  scs_sync<ONEWAVE>();
   st = unit_lane ? s.status[lane] : 99;
   int stage = s.stage, turn = s.turn;
   const int target = s.target;
@@ -552,7 +566,7 @@ __device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, in
     }
     break;
   }
-  __syncthreads();
+  scs_sync<ONEWAVE>();
   if (lane == 0) {
     s.turn = (int16_t)turn;
     s.player = (stage == -2 || (stage >= 0 && stage <= 3)) ? 0 : 1;
@@ -564,7 +578,7 @@ __device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, in
                   : (stage == 1 || stage == 5) ? 1 : (stage == 2 || stage == 6) ? 2 : 3;
     s.stage = (int16_t)stage;
   }
-  __syncthreads();
+  scs_sync<ONEWAVE>();
 }
 
 }  // namespace nz

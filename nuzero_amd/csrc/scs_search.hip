@@ -25,6 +25,7 @@
 
 #include "../../include/nuzero_amd.h"
 #include "scs_dev.hpp"
+#include "boardnet_internal.h"
 
 using namespace nz;
 
@@ -682,6 +683,496 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   leave((unsigned long long)n_sim + n_expanded);
 }
 
+
+// ---- persistent self-play: one wavefront per game, the whole move's search in one launch --------------------------------
+// wave_kernel + a network launch per simulation make every game wait for the slowest of all games, a thousand times a
+// move.  Here a game's wavefront runs its simulations on its own (Explorer.run_mcts, :49-61: one in flight per tree):
+// descent and rules as in wave_kernel, then the NETWORK FOR ITS OWN LEAF -- the split-bf16 arithmetic of
+// fused16_net_kernel (boardnet.hip) for one position: 25 cells = two row tiles, every layer's weights streamed from L2,
+// activations in the wavefront's own block of LDS -- softmax, expansion, backup, next simulation.  No barrier, no other
+// game, no host until the move's simulations are used up.  Four games (wavefronts) per workgroup share the rules block.
+struct PersistArgs {
+  const Fused16Program* prog;
+  int32_t net_floats, stage_off, stage_floats, inp, in_channels;
+  int32_t wave_bytes;             // a wavefront's LDS block: real game, scratch game, legal mask, legal list, network
+  // leaf evaluations of chosen games, for the oracle replay of tests/scs_replay.py (null: none)
+  const int32_t* rec_slot;        // [G] slot or -1
+  int32_t rec_cap;
+  int32_t* rec_count;             // [slots]
+  uint64_t* rec_digest;           // [slots][cap][2] image_hash_wave of the leaf's float32 planes
+  float* rec_probs;               // [slots][cap][A]
+  float* rec_value;               // [slots][cap]
+};
+constexpr int PERSIST_GAMES = 4;                 // wavefronts (games) per workgroup
+constexpr int PERSIST_STATE_BYTES = (int)((sizeof(ScsState) + 15) / 16 * 16);
+constexpr int PERSIST_MASK_BYTES = (MASK_WORDS * 4 + 15) / 16 * 16;
+constexpr int PERSIST_GAME_BYTES = 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES + MAXC_LIMIT * 4;
+constexpr int PERSIST_RULES_BYTES = (int)((sizeof(ScsRules) + 15) / 16 * 16);
+typedef const __attribute__((address_space(1))) u32x4* gptr4u;
+
+// 128-bit digest of a leaf's float32 planes [channels][tiles] as they sit in the staging rows ([tile][inp]); order-free
+// sums of per-element mixes, so any lane order gives the same value (tests/scs_replay.py image_mix_digest is its twin)
+__device__ __forceinline__ void image_hash_wave(const float* stage, int inp, int channels, int tiles, int lane, uint64_t& hi, uint64_t& lo) {
+  uint64_t a = 0, b = 0;
+  for (int i = lane; i < channels * tiles; i += 64) {
+    const int c = i / tiles, t = i - c * tiles;
+    const uint64_t v = ((uint64_t)(uint32_t)i << 32) | __builtin_bit_cast(uint32_t, stage[t * inp + c]);
+    a += mix64(v ^ 0x9e3779b97f4a7c15ull);
+    b += mix64(v * 0xd6e8feb86659fd93ull + 0x2545f4914f6cdd1dull);
+  }
+  for (int o = 32; o; o >>= 1) {
+    a += __shfl_xor((unsigned long long)a, o, 64);
+    b += __shfl_xor((unsigned long long)b, o, 64);
+  }
+  hi = mix64(a ^ (b >> 7));
+  lo = mix64(b ^ (a << 9));
+}
+
+// One conv layer's K loop for one position: 2 row tiles x NT column tiles, NTAPS x KGT steps as straight-line code.
+// Activations (the MFMA's second operand) come from LDS, this lane's operand row per tap in srow; the weights (first
+// operand) straight from the packed L2 stream, their loads running AHEAD steps in front of the MFMAs that use them.
+template <int NTAPS, int KGT, int NT>
+__device__ __forceinline__ void wave_conv(f32x4 (&acc)[2][NT], const float* __restrict__ net, const int (&srow)[2][NTAPS],
+                                          int off0, int cs0, int ps0, int kq, const uint32_t* __restrict__ wg) {
+  constexpr int STEPS = NTAPS * KGT;
+  constexpr int AHEAD = 3;
+  u32x4 bq[AHEAD + 1][NT][3];
+#pragma unroll
+  for (int st = 0; st < AHEAD && st < STEPS; ++st)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) bq[st][ct][piece] = *((gptr4u)(wg + ((ct * STEPS + st) * 3 + piece) * 256));
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+#pragma unroll
+    for (int kg = 0; kg < KGT; ++kg) {
+      const int st = tap * KGT + kg;
+      u32x4 a[2][3];
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const int r = srow[rt][tap];
+        const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
+#pragma unroll
+        for (int piece = 0; piece < 3; ++piece) a[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
+      }
+      if (st + AHEAD < STEPS) {
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+          for (int piece = 0; piece < 3; ++piece)
+            bq[(st + AHEAD) % (AHEAD + 1)][ct][piece] = *((gptr4u)(wg + ((ct * STEPS + st + AHEAD) * 3 + piece) * 256));
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) step16(acc[rt][ct], a[rt], bq[st % (AHEAD + 1)][ct]);
+    }
+  }
+}
+
+// residual, activation, split into pieces (or float32 rows), store: fused16_net_kernel's epilogue for one tile
+__device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restrict__ net, const Fused16Op& op, int rt, int ct,
+                                              int lane, int rows) {
+  const int orow = rt * 16 + (lane & 15), c0 = ct * 16 + (lane >> 4) * 4;
+  if (orow >= rows) return;
+  const int chunk = (((c0 >> 3) ^ ((orow >> 2) & 3)) << 2) + ((c0 & 7) >> 1);
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = acc[r];
+  if (op.offr >= 0) {
+    const float* rp = net + op.offr + orow * op.csr + chunk;
+    const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + op.psr),
+                q2 = *reinterpret_cast<const uint2*>(rp + 2 * op.psr);
+    auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+    auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
+    v[0] += (lo(q0.x) + lo(q1.x)) + lo(q2.x);
+    v[1] += (hi(q0.x) + hi(q1.x)) + hi(q2.x);
+    v[2] += (lo(q0.y) + lo(q1.y)) + lo(q2.y);
+    v[3] += (hi(q0.y) + hi(q1.y)) + hi(q2.y);
+  }
+  switch (op.act) {
+    case 1:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      break;
+    case 2:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = tanhf(v[r]);
+      break;
+    case 3:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : fast_expm1(v[r]);
+      break;
+    default: break;
+  }
+  if (op.psd == 0) {
+    *reinterpret_cast<f32x4*>(net + op.offd + orow * op.csd + c0) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    uint16_t h3[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) split3_bits(v[r], h3[r]);
+    float* dp = net + op.offd + orow * op.csd + chunk;
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece)
+      *reinterpret_cast<uint2*>(dp + piece * op.psd) =
+          uint2{(uint32_t)h3[0][piece] | ((uint32_t)h3[1][piece] << 16), (uint32_t)h3[2][piece] | ((uint32_t)h3[3][piece] << 16)};
+  }
+}
+
+template <int NTAPS, int KGT, int NT>
+__device__ __forceinline__ void wave_layer_part(float* __restrict__ net, const Fused16Op& op, const int (&srow)[2][NTAPS], int ct0,
+                                                int lane, int rows) {
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  wave_conv<NTAPS, KGT, NT>(acc, net, srow, op.off0, op.cs0, op.ps0, lane >> 4, op.w + (size_t)ct0 * op.w_chunks * 4 + lane * 4);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) wave_epilogue(acc[rt][ct], net, op, rt, ct0 + ct, lane, rows);
+}
+
+// every layer of the network for the position whose input pieces sit in this wavefront's block
+template <bool HEX>
+__device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
+                                             int H, int Wd, int lane) {
+  constexpr int ntaps = HEX ? 7 : 9;
+  int srow[2][ntaps];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    const int row = rt * 16 + (lane & 15);
+    const bool row_ok = row < rows;
+    const int cy = row / Wd, cx = row - cy * Wd;
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+      srow[rt][tap] = on ? row + dy * Wd + dx : rows;       // (row index `rows`: every buffer's row of zeros)
+    }
+  }
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
+  static_assert(OP_DWORDS <= 64, "one dword per lane");
+  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
+  uint32_t dvec = lane < OP_DWORDS ? ops_words[lane] : 0u;
+  for (int o = 0; o < n_ops; ++o) {
+    Fused16Op op;
+    {
+      uint32_t words[OP_DWORDS];
+#pragma unroll
+      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
+      __builtin_memcpy(&op, words, sizeof(Fused16Op));
+    }
+    if (o + 1 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 1) * OP_DWORDS + lane];
+    const int kgt = op.kg0;
+    for (int ct0 = 0; ct0 < op.ntiles; ct0 += 2) {
+      const bool two = ct0 + 1 < op.ntiles;
+      if (two) {
+        if (kgt == 1) wave_layer_part<ntaps, 1, 2>(net, op, srow, ct0, lane, rows);
+        else if (kgt == 2) wave_layer_part<ntaps, 2, 2>(net, op, srow, ct0, lane, rows);
+        else if (kgt == 3) wave_layer_part<ntaps, 3, 2>(net, op, srow, ct0, lane, rows);
+        else wave_layer_part<ntaps, 4, 2>(net, op, srow, ct0, lane, rows);
+      } else {
+        if (kgt == 1) wave_layer_part<ntaps, 1, 1>(net, op, srow, ct0, lane, rows);
+        else if (kgt == 2) wave_layer_part<ntaps, 2, 1>(net, op, srow, ct0, lane, rows);
+        else if (kgt == 3) wave_layer_part<ntaps, 3, 1>(net, op, srow, ct0, lane, rows);
+        else wave_layer_part<ntaps, 4, 1>(net, op, srow, ct0, lane, rows);
+      }
+    }
+    scs_sync<false>();                    // the layer's stores are ordered before the next layer's reads (same wavefront)
+  }
+}
+
+template <bool HEX>
+__global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParams p, PersistArgs q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ScsRules& R = *reinterpret_cast<ScsRules*>(smem);
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  {   // rules -> LDS, once per workgroup; the only workgroup barrier of the kernel
+    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_GAMES * 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const int g = blockIdx.x * PERSIST_GAMES + wave;
+  if (g >= p.n_games) return;
+  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)wave * q.wave_bytes;
+  ScsState& real_l = *reinterpret_cast<ScsState*>(wb);
+  ScsState& sc = *reinterpret_cast<ScsState*>(wb + PERSIST_STATE_BYTES);
+  uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
+  int* const sidx = reinterpret_cast<int*>(wb + 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES);
+  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
+  if (p.real[g].terminal) return;
+  int sims_left = p.sims_left[g];
+  if (sims_left <= 0) return;
+  const int root = p.root[g];
+  int base = p.node_count[g];
+  int32_t* const path = p.path + (size_t)g * p.max_path;
+  SNode* const nodes = arena(p, g);
+  const int A = p.num_actions;
+  {   // the real game and a clean network block
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(&p.real[g]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&real_l);
+    for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) dst[i] = src[i];
+    for (int i = lane * 4; i < q.net_floats; i += 256) *reinterpret_cast<f32x4*>(net + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int rec = q.rec_slot ? q.rec_slot[g] : -1;
+  int rec_n = rec >= 0 ? q.rec_count[rec] : 0;
+  // the program's header, one dword per lane
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
+  static_assert(HDR_DWORDS <= 64, "one dword per lane");
+  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
+#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
+  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops), planes = PHDR(planes);
+  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs), in_ps = PHDR(in_ps);
+  const int pol_off = PHDR(pol_off), pp = PHDR(pol_cs), val_off = PHDR(val_off), vp = PHDR(val_cs);
+#undef PHDR
+  scs_sync<false>();
+  unsigned long long n_sim = 0, n_exp = 0;
+  bool failed = false;
+
+  while (sims_left > 0) {
+    {   // scratch_game = game.shallow_clone()
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&real_l);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(&sc);
+      for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) dst[i] = src[i];
+      scs_sync<false>();
+    }
+    int node = root, plen = 1;
+    int my_path = root;                         // lane i holds path[i] (levels past 63 go to memory)
+    bool bad = false;
+    int par_visit, par_base, par_k, par_to_play;
+    {
+      const SNode r0 = nodes[root];
+      par_visit = r0.visit; par_base = r0.child_base; par_k = r0.n_children; par_to_play = r0.to_play;
+    }
+    while (par_k > 0) {
+      if (par_visit >= p.tab_len || plen >= p.max_path) { bad = true; break; }
+      const double sq = p.sqrt_tab[par_visit], cb = p.bias_tab[par_visit];
+      const bool negate = par_to_play == p.negate_player;
+      double score = -INFINITY;
+      int key = -1;
+      int b_visit = 0, b_base = 0, b_k = 0, b_to_play = 0;
+      for (int j = lane; j < par_k; j += 64) {
+        const SNode c = nodes[par_base + j];
+        const double scv = child_score(p, c, sq, cb, negate);
+        const int ky = ((int)c.action << 8) | j;
+        if (scv > score || (scv == score && ky > key)) {
+          score = scv; key = ky;
+          b_visit = c.visit; b_base = c.child_base; b_k = c.n_children; b_to_play = c.to_play;
+        }
+      }
+      const int my_key = key;
+      for (int w = 32; w >= 1; w >>= 1) {
+        const double os = __shfl_xor(score, w, 64);
+        const int ok = __shfl_xor(key, w, 64);
+        if (os > score || (os == score && ok > key)) { score = os; key = ok; }
+      }
+      const unsigned long long holders = __ballot(my_key == key);
+      const int wl = __builtin_amdgcn_readfirstlane(__ffsll((long long)holders) - 1);
+      node = par_base + (key & 0xff);
+      par_visit = __builtin_amdgcn_readlane(b_visit, wl);
+      par_base = __builtin_amdgcn_readlane(b_base, wl);
+      par_k = __builtin_amdgcn_readlane(b_k, wl);
+      par_to_play = __builtin_amdgcn_readlane(b_to_play, wl);
+      if (plen < 64) { if (lane == plen) my_path = node; }
+      else if (lane == 0) path[plen] = node;
+      scs_step_wave<false>(R, sc, key >> 8, lane);
+      ++plen;
+    }
+    if (bad) {
+      if (lane == 0) atomicOr(p.error_flag, 2);
+      failed = true;
+      break;
+    }
+    scs_sync<false>();
+    const int to_play = sc.player, term = sc.terminal;
+    double v;
+    if (term) {                                 // Explorer.py:140-142: the stored terminal value, no network
+      if (lane == 0) {
+        nodes[node].to_play = (int8_t)to_play;
+        nodes[node].terminal = 1;
+      }
+      v = (double)sc.terminal_value;
+    } else {
+      if (lane == 0) nodes[node].to_play = (int8_t)to_play;
+      // legal actions: mask, then the ascending list (Explorer.py:163-165)
+      scs_legal_mask_wave<MASK_WORDS, false>(R, sc, smask, lane);
+      int k = 0;
+#pragma unroll
+      for (int w = 0; w < (MASK_WORDS + 63) / 64; ++w) {
+        uint32_t bits = w * 64 + lane < MASK_WORDS ? smask[w * 64 + lane] : 0u;
+        int inc = __popc(bits);
+        for (int d = 1; d < 64; d <<= 1) {
+          const int o = __shfl_up(inc, d, 64);
+          if (lane >= d) inc += o;
+        }
+        int off = k + inc - __popc(bits);
+        while (bits) {
+          const int b = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (off < MAXC_LIMIT) sidx[off] = (w * 64 + lane) * 32 + b;
+          ++off;
+        }
+        k += __shfl(inc, 63, 64);
+      }
+      const bool overflow = k > p.maxc;
+      if (overflow || base + k > p.half_cap) {
+        if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
+        failed = true;
+        break;
+      }
+      // the leaf's planes (generate_network_input, SCS_Game.py:1507): float32 rows over the trunk buffers' space, split
+      // into the input pieces, then that space is zeros again (the buffers' rows of zeros, channels no layer writes)
+      float* const stage = net + q.stage_off;
+      scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
+      scs_sync<false>();
+      uint64_t dig_hi = 0, dig_lo = 0;
+      if (rec >= 0) image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
+      {
+        const int chunks = q.inp >> 3;
+        for (int i = lane; i < (hw + 1) * chunks; i += 64) {
+          const int r = i / chunks, c8 = i - r * chunks;
+          u32x4 q0 = u32x4{0u, 0u, 0u, 0u}, q1 = q0, q2 = q0;
+          if (r < hw) {
+            f32x4 lo4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8);
+            f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (c8 * 8 + j >= q.in_channels) lo4[j] = 0.f;
+              if (c8 * 8 + 4 + j >= q.in_channels) hi4[j] = 0.f;
+            }
+            wide_split8(lo4, hi4, q0, q1, q2);
+          }
+          float* d = net + in_off + r * in_cs + ((c8 ^ ((r >> 2) & 3)) << 2);
+          *reinterpret_cast<u32x4*>(d) = q0;
+          *reinterpret_cast<u32x4*>(d + in_ps) = q1;
+          *reinterpret_cast<u32x4*>(d + 2 * in_ps) = q2;
+        }
+      }
+      scs_sync<false>();
+      for (int i = lane * 4; i < q.stage_floats; i += 256) *reinterpret_cast<f32x4*>(stage + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+      scs_sync<false>();
+      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane);
+      // softmax over ALL logits (Explorer.py:158-160) and value = tanh(mean of the value plane) (blocks.py:82-84)
+      float* const pol = net + pol_off;
+      float mx = -INFINITY;
+      for (int i = lane; i < A; i += 64) {
+        const int plane = i / hw, cell = i - plane * hw;
+        mx = fmaxf(mx, pol[cell * pp + plane]);
+      }
+      for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w, 64));
+      // the sum in fused16_net_kernel's order for a workgroup of up to four positions (four wavefronts per position, each
+      // lane adding every 256th entry, a butterfly per wavefront, the four partial sums added in turn), so that a game
+      // plays the same moves on either route
+      float part[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int i0 = 0; i0 < A; i0 += 256) {
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub) {
+          const int i = i0 + sub * 64 + lane;
+          if (i < A) {
+            const int plane = i / hw, cell = i - plane * hw;
+            const float e = expf(pol[cell * pp + plane] - mx);
+            pol[cell * pp + plane] = e;
+            part[sub] += e;
+          }
+        }
+      }
+      float sum = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        float ps = part[sub];
+        for (int w = 32; w; w >>= 1) ps += __shfl_xor(ps, w, 64);
+        sum += ps;
+      }
+      float sv = lane < hw ? net[val_off + lane * vp] : 0.f;
+      for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w, 64);
+      const float value = tanhf(sv / (float)hw);
+      v = (double)value;
+      (void)planes;
+      scs_sync<false>();
+      if (rec >= 0) {
+        if (rec_n < q.rec_cap) {
+          const size_t at = (size_t)rec * q.rec_cap + rec_n;
+          for (int i = lane; i < A; i += 64) {
+            const int plane = i / hw, cell = i - plane * hw;
+            q.rec_probs[at * A + i] = pol[cell * pp + plane] / sum;
+          }
+          if (lane == 0) { q.rec_value[at] = value; q.rec_digest[2 * at] = dig_hi; q.rec_digest[2 * at + 1] = dig_lo; }
+        }
+        ++rec_n;
+      }
+      // expansion (Explorer.py:162-181): child j = the j-th legal action, prior = masked prob / their float32 np.sum
+      int my_idx[MAXC_CHUNKS];
+      float my_val[MAXC_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        my_idx[c] = j < k ? sidx[j] : 0x7fffffff;
+        float pr = 0.0f;
+        if (j < k) {
+          const int plane = my_idx[c] / hw, cell = my_idx[c] - plane * hw;
+          pr = pol[cell * pp + plane] / sum;
+        }
+        my_val[c] = pr;
+      }
+      float total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
+      if (total == 0.0f) {
+#pragma unroll
+        for (int c = 0; c < MAXC_CHUNKS; ++c) my_val[c] = my_val[c] + 1.0f;
+        total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
+      }
+#pragma unroll
+      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+        const int j = c * 64 + lane;
+        if (j < k) {
+          SNode n;
+          n.prior = (double)(my_val[c] / total);
+          n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = (uint16_t)my_idx[c];
+          n.to_play = -1; n.prior_f64 = 0; n.terminal = 0; n.pad = 0;
+          nodes[base + j] = n;
+        }
+      }
+      if (lane == 0) {
+        nodes[node].child_base = base;
+        nodes[node].n_children = (uint16_t)k;
+      }
+      base += k;
+      ++n_exp;
+    }
+    // backup (Explorer.py:132-135): the same value to every node of the path, root included
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < plen && lane < 64) {
+      SNode& n = nodes[my_path];
+      n.visit += 1;
+      n.value_sum = n.value_sum + v;
+    }
+    for (int i = 64 + lane; i < plen; i += 64) {
+      SNode& n = nodes[path[i]];
+      n.visit += 1;
+      n.value_sum = n.value_sum + v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    --sims_left;
+    ++n_sim;
+  }
+  if (lane == 0) {
+    p.sims_left[g] = failed ? sims_left : 0;
+    p.pending[g] = -1;
+    p.node_count[g] = base;
+    if (rec >= 0) q.rec_count[rec] = rec_n;
+    if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], n_sim);
+    if (n_exp) atomicAdd((unsigned long long*)&p.counters[1], n_exp);
+  }
+}
+
 __global__ void search_status_kernel(SearchParams p, int32_t* out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= p.n_games) return;
@@ -844,6 +1335,13 @@ struct nz_scs_search {
   int cache_bits = 0;
   int64_t cache_entries = 0;
   int32_t cache_wave = 0;
+  // persistent route (persist_kernel): -1 follow the default (on where the network has a per-wavefront form), 0 off, 1 on
+  int persist_mode = -1;
+  int persist_used = 0;                       // the last play ran on it
+  std::string persist_why;                    // why not
+  PersistArgs pq{};
+  int32_t* rec_slot_dev = nullptr;
+  int32_t rec_slots = 0;
 };
 
 namespace {
@@ -1032,6 +1530,10 @@ void nz_scs_search_destroy(nz_scs_search* h) {
       if (q) (void)hipFree(q);
   }
   if (h->p.c_id) { (void)hipFree(h->p.c_id); (void)hipFree(h->p.c_probs); (void)hipFree(h->p.c_value); (void)hipFree(h->p.c_writer); }
+  if (h->rec_slot_dev) {
+    (void)hipFree(h->rec_slot_dev); (void)hipFree(h->pq.rec_count); (void)hipFree(h->pq.rec_digest);
+    (void)hipFree(h->pq.rec_probs); (void)hipFree(h->pq.rec_value);
+  }
   delete h;
 }
 
@@ -1201,6 +1703,39 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
                     dalloc(h, &h->noise, (size_t)G * MAXC) && dalloc(h, &h->uniforms, (size_t)G * 3);
     if (!ok) return sfail(h, NZ_ERR_HIP, "device allocation failed");
   }
+  // the persistent route: the network must have a per-wavefront form and the inference cache must be off (the table is
+  // only ever written between two launches)
+  bool persist = false;
+  size_t persist_lds = 0;
+  h->persist_used = 0;
+  {
+    static const int env_mode = getenv("NZ_SCS_PERSIST") ? atoi(getenv("NZ_SCS_PERSIST")) : -1;       // A/B experiments
+    const int mode = h->persist_mode >= 0 ? h->persist_mode : env_mode;
+    nz::WaveNet wn{};
+    std::string why;
+    if (mode == 0) h->persist_why = "switched off";
+    else if (h->cache_bits > 0) h->persist_why = "the inference cache is on";
+    else if (!nz::boardnet_wave_program(net, &wn, &why)) h->persist_why = why;
+    else {
+      PersistArgs& q = h->pq;
+      q.prog = wn.prog; q.net_floats = wn.lds_floats; q.stage_off = wn.stage_off; q.stage_floats = wn.stage_floats;
+      q.inp = wn.inp; q.in_channels = wn.in_channels;
+      q.wave_bytes = PERSIST_GAME_BYTES + (wn.lds_floats * 4 + 15) / 16 * 16;
+      persist_lds = (size_t)PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
+      if (persist_lds > 160 * 1024) h->persist_why = "four games' blocks do not fit in LDS";
+      else {
+        const hipError_t e = wn.hex
+            ? hipFuncSetAttribute((const void*)persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds)
+            : hipFuncSetAttribute((const void*)persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
+        if (e != hipSuccess) { (void)hipGetLastError(); h->persist_why = "hipFuncSetAttribute failed"; }
+        else { persist = true; h->persist_why.clear(); }
+      }
+      if (persist) h->persist_used = wn.hex ? 2 : 1;
+    }
+    if (mode == 1 && !persist) return sfail(h, NZ_ERR_STATE, "persistent route requested but not available: %s", h->persist_why.c_str());
+    if (h->rec_slot_dev && !persist) return sfail(h, NZ_ERR_STATE, "leaf recording needs the persistent route: %s", h->persist_why.c_str());
+  }
+  h->pq.rec_slot = h->rec_slot_dev;
   std::vector<nz_rng*> rngs;
   struct RngGuard {
     std::vector<nz_rng*>& v;
@@ -1299,6 +1834,17 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     h->p.c_bits = h->cache_bits;
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
+    if (persist) {                               // the whole move's search of every game: one launch
+      if (h->persist_used == 2)
+        hipLaunchKernelGGL(persist_kernel<true>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
+      else
+        hipLaunchKernelGGL(persist_kernel<false>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
+      S_HIP(h, hipGetLastError());
+      ++h->waves;
+      st = nz_scs_search_end_move(h, h->uniforms, stream);
+      if (st != NZ_OK) return st;
+      continue;
+    }
     const int sims = h->cfg.mcts_simulations;
     bool poll_pending = false;
     if (!h->active_pinned) {
@@ -1450,6 +1996,61 @@ nz_status nz_scs_search_phase_ticks(nz_scs_search* h, int64_t* out6_host) {
   S_HIP(h, hipSetDevice(h->device));
   S_HIP(h, hipDeviceSynchronize());
   S_HIP(h, hipMemcpy(out6_host, h->p.counters + 2, 6 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return NZ_OK;
+}
+
+// The persistent route of the library's move loop (persist_kernel).  enable: 1 require it (a play then fails where it is
+// not available), 0 never use it, -1 the default (use it where it is available).  *used: whether the last play ran on it.
+nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* used) {
+  if (!h) return NZ_ERR_ARG;
+  if (enable >= -1 && enable <= 1) h->persist_mode = enable;
+  if (used) *used = h->persist_used ? 1 : 0;
+  return NZ_OK;
+}
+
+// Test hook of the persistent route: keep the leaf evaluations (digest of the planes, post-softmax probabilities, value)
+// of `n` games, up to `capacity` each, in the order the game's search consumed them.  n = 0: stop recording.
+nz_status nz_scs_search_record(nz_scs_search* h, const int32_t* games_host, int32_t n, int32_t capacity) {
+  if (!h || n < 0 || (n > 0 && (!games_host || capacity <= 0))) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  if (h->rec_slot_dev) {
+    (void)hipFree(h->rec_slot_dev); (void)hipFree(h->pq.rec_count); (void)hipFree(h->pq.rec_digest);
+    (void)hipFree(h->pq.rec_probs); (void)hipFree(h->pq.rec_value);
+    h->rec_slot_dev = nullptr; h->pq.rec_count = nullptr; h->pq.rec_digest = nullptr; h->pq.rec_probs = nullptr; h->pq.rec_value = nullptr;
+    h->rec_slots = 0;
+  }
+  h->pq.rec_slot = nullptr;
+  if (n == 0) return NZ_OK;
+  std::vector<int32_t> slot(h->n_games, -1);
+  for (int i = 0; i < n; ++i) {
+    if (games_host[i] < 0 || games_host[i] >= h->n_games) return sfail(h, NZ_ERR_ARG, "no game %d", games_host[i]);
+    slot[games_host[i]] = i;
+  }
+  const size_t A = (size_t)h->p.num_actions, N = (size_t)n * capacity;
+  if (hipMalloc((void**)&h->rec_slot_dev, slot.size() * 4) != hipSuccess || hipMalloc((void**)&h->pq.rec_count, (size_t)n * 4) != hipSuccess ||
+      hipMalloc((void**)&h->pq.rec_digest, N * 16) != hipSuccess || hipMalloc((void**)&h->pq.rec_probs, N * A * 4) != hipSuccess ||
+      hipMalloc((void**)&h->pq.rec_value, N * 4) != hipSuccess)
+    return sfail(h, NZ_ERR_HIP, "device allocation failed (recording %d games x %d evaluations)", n, capacity);
+  S_HIP(h, hipMemcpy(h->rec_slot_dev, slot.data(), slot.size() * 4, hipMemcpyHostToDevice));
+  S_HIP(h, hipMemset(h->pq.rec_count, 0, (size_t)n * 4));
+  h->pq.rec_cap = capacity;
+  h->rec_slots = n;
+  return NZ_OK;
+}
+
+// one recorded game: *count evaluations were consumed (those past the capacity are not kept); the arrays take
+// min(*count, capacity) rows.  Host pointers; synchronises.
+nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* count, uint64_t* digests_host, float* probs_host,
+                                    float* values_host) {
+  if (!h || !count || slot < 0 || slot >= h->rec_slots) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  S_HIP(h, hipMemcpy(count, h->pq.rec_count + slot, 4, hipMemcpyDeviceToHost));
+  const size_t n = (size_t)std::min(*count, h->pq.rec_cap), A = (size_t)h->p.num_actions, at = (size_t)slot * h->pq.rec_cap;
+  if (digests_host) S_HIP(h, hipMemcpy(digests_host, h->pq.rec_digest + 2 * at, n * 16, hipMemcpyDeviceToHost));
+  if (probs_host) S_HIP(h, hipMemcpy(probs_host, h->pq.rec_probs + at * A, n * A * 4, hipMemcpyDeviceToHost));
+  if (values_host) S_HIP(h, hipMemcpy(values_host, h->pq.rec_value + at, n * 4, hipMemcpyDeviceToHost));
   return NZ_OK;
 }
 

@@ -341,6 +341,37 @@ class ScsSelfPlay:
         out["waves"] = int(waves.value)
         return out
 
+    def persistent(self, enable=-1):
+        """The library's move loop on the persistent kernel (one wavefront per game, a move's whole search in one
+        launch): 1 require it, 0 never, -1 the default (where the network has a per-wavefront form and the inference
+        cache is off).  Returns whether the LAST play ran on it."""
+        used = ctypes.c_int32(0)
+        self._check(lib.nz_scs_search_persistent(self._h, int(enable), byref(used)))
+        return bool(used.value)
+
+    def record(self, games, capacity):
+        """Test hook of the persistent route: keep the leaf evaluations of `games` (indices), up to `capacity` each,
+        in the order each game's search consumes them (nz_scs_search_record); games = [] stops recording."""
+        games = np.ascontiguousarray(np.asarray(list(games), dtype=np.int32))
+        self._recorded = [int(g) for g in games]
+        self._check(lib.nz_scs_search_record(self._h, c_void_p(games.ctypes.data), len(games), int(capacity)))
+        self._record_capacity = int(capacity)
+
+    def records(self):
+        """{game: (digests uint64 [n, 2], probs float32 [n, A], values float32 [n])} of the recorded games."""
+        out, A = {}, self.cfg.planes * self.cfg.rows * self.cfg.cols
+        for slot, g in enumerate(self._recorded):
+            count = ctypes.c_int32(0)
+            self._check(lib.nz_scs_search_record_read(self._h, slot, byref(count), None, None, None))
+            if count.value > self._record_capacity:
+                raise RuntimeError(f"game {g} consumed {count.value} evaluations, capacity {self._record_capacity}")
+            n = count.value
+            dig, pr, va = np.empty((n, 2), np.uint64), np.empty((n, A), np.float32), np.empty((n,), np.float32)
+            self._check(lib.nz_scs_search_record_read(self._h, slot, byref(count), c_void_p(dig.ctypes.data),
+                                                      c_void_p(pr.ctypes.data), c_void_p(va.ctypes.data)))
+            out[g] = (dig, pr, va)
+        return out
+
     def play_round(self, net, seeds):
         """A round of len(seeds) >= n_games games over this engine's n_games slots (nz_scs_search_play_round): a slot
         whose game has ended starts the round's next game, as a Gamer actor plays its games back to back

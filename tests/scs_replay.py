@@ -22,6 +22,31 @@ def image_digest(img):
     return hashlib.blake2b(np.ascontiguousarray(img, dtype=np.float32).tobytes(), digest_size=8).digest()
 
 
+def _mix64(x):
+    """murmur3's finaliser on uint64 arrays (wrap-around arithmetic), the twin of mix64 in scs_search.hip."""
+    x = x.astype(np.uint64).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xff51afd7ed558ccd)
+        x ^= x >> np.uint64(33)
+        x *= np.uint64(0xc4ceb9fe1a85ec53)
+        x ^= x >> np.uint64(33)
+    return x
+
+
+def image_mix_digest(img):
+    """The 128-bit digest the persistent kernel records of a leaf's float32 planes (image_hash_wave, scs_search.hip):
+    order-free sums of per-element mixes of (flat NCHW index, float bits).  Returns uint64 [2] (hi, lo)."""
+    bits = np.ascontiguousarray(img, dtype=np.float32).reshape(-1).view(np.uint32).astype(np.uint64)
+    v = (np.arange(len(bits), dtype=np.uint64) << np.uint64(32)) | bits
+    with np.errstate(over="ignore"):
+        a = _mix64(v ^ np.uint64(0x9e3779b97f4a7c15)).sum(dtype=np.uint64)
+        b = _mix64(v * np.uint64(0xd6e8feb86659fd93) + np.uint64(0x2545f4914f6cdd1d)).sum(dtype=np.uint64)
+        hi = _mix64(np.array([a ^ (b >> np.uint64(7))], np.uint64))[0]
+        lo = _mix64(np.array([b ^ (a << np.uint64(9))], np.uint64))[0]
+    return np.array([hi, lo], np.uint64)
+
+
 class LeafRecorder:
     def __init__(self, evaluator, games=None):
         """games: the game indices to record (None: all)."""
@@ -59,7 +84,11 @@ def replay_game(args):
         i = cursor[0]
         if i >= len(values):
             raise AssertionError("the oracle asks for more evaluations than the device search used")
-        if image_digest(g.state_image()[0]) != digests[i].tobytes():
+        if digests.dtype == np.uint64:           # recorded by the persistent kernel itself (nz_scs_search_record)
+            same = np.array_equal(image_mix_digest(g.state_image()[0]), digests[i])
+        else:
+            same = image_digest(g.state_image()[0]) == digests[i].tobytes()
+        if not same:
             raise AssertionError(f"leaf {i}: the oracle's leaf image is not the one the device evaluated")
         cursor[0] = i + 1
         return probs[i], values[i]
