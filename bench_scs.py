@@ -201,6 +201,7 @@ def main():
         out["cache"] = sp.cache_stats()
     if os.environ.get("NZ_LIB_PATH") and args.streams == 1:      # a diagnostic build may carry the wave kernel's phase stamps
         out["wave_kernel_phase_ticks"] = sp.phase_ticks()
+        out["persist_kernel_ticks"] = sp.persist_ticks()
     print(json.dumps({"workload": "SCS %dx%d stack %d, %d sims/move, %d concurrent games, %s, %s convs), %s evaluator, "
                                   "%s move loop" % (cfg.rows, cfg.cols, cfg.stacking, args.sims, args.games, net_name,
                                                     "hexagonal (unpinned)" if args.hex else "square",

@@ -451,6 +451,11 @@ nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* us
  * each, in the order the game's search consumed them; n = 0 stops.  nz_scs_search_record_read (host pointers, any of the
  * three arrays may be NULL): *count evaluations consumed, digests uint64 [.][2] (a 128-bit mix of the leaf's float32
  * planes), probs float32 [.][A] post-softmax, values float32 [.]; rows = min(*count, capacity). */
+/* Diagnostic (library built with -DNZ_PERSIST_STAMPS; zeros otherwise): shader ticks of the persistent route summed over
+ * games and moves since the last reset: clone, descent, legal mask + list, planes + split, network, softmax + value,
+ * expansion, backup, whole moves, the slowest single (game, move); inside the network (leader's half): K loops,
+ * epilogues, waits for the helper.  13 values. */
+nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out13_host);
 nz_status nz_scs_search_record(nz_scs_search* h, const int32_t* games_host, int32_t n, int32_t capacity);
 nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* count, uint64_t* digests_host,
                                     float* probs_host, float* values_host);

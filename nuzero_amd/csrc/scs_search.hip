@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -703,10 +704,14 @@ struct PersistArgs {
   float* rec_probs;               // [slots][cap][A]
   float* rec_value;               // [slots][cap]
 };
-constexpr int PERSIST_GAMES = 4;                 // wavefronts (games) per workgroup
+constexpr int PERSIST_GAMES = 4;                 // games per workgroup
+constexpr int PERSIST_WAVES = 2 * PERSIST_GAMES;  // a leader and a helper wavefront per game
+constexpr int PERSIST_THREADS = PERSIST_WAVES * 64;
+constexpr int PERSIST_FLAG_BYTES = 16;           // per game: the two step numbers of pair_sync, the pass number / exit word
+constexpr int PERSIST_EXIT = 0x7fffffff;
 constexpr int PERSIST_STATE_BYTES = (int)((sizeof(ScsState) + 15) / 16 * 16);
 constexpr int PERSIST_MASK_BYTES = (MASK_WORDS * 4 + 15) / 16 * 16;
-constexpr int PERSIST_GAME_BYTES = 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES + MAXC_LIMIT * 4;
+constexpr int PERSIST_GAME_BYTES = 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES + MAXC_LIMIT * 4 + PERSIST_FLAG_BYTES;
 constexpr int PERSIST_RULES_BYTES = (int)((sizeof(ScsRules) + 15) / 16 * 16);
 typedef const __attribute__((address_space(1))) u32x4* gptr4u;
 
@@ -728,46 +733,62 @@ __device__ __forceinline__ void image_hash_wave(const float* stage, int inp, int
   lo = mix64(b ^ (a << 9));
 }
 
-// One conv layer's K loop for one position: 2 row tiles x NT column tiles, NTAPS x KGT steps as straight-line code.
-// Activations (the MFMA's second operand) come from LDS, this lane's operand row per tap in srow; the weights (first
-// operand) straight from the packed L2 stream, their loads running AHEAD steps in front of the MFMAs that use them.
-template <int NTAPS, int KGT, int NT>
-__device__ __forceinline__ void wave_conv(f32x4 (&acc)[2][NT], const float* __restrict__ net, const int (&srow)[2][NTAPS],
-                                          int off0, int cs0, int ps0, int kq, const uint32_t* __restrict__ wg) {
+// One conv layer's K loop for one position and ONE column tile: both row tiles (25 cells), NTAPS x KGT steps as
+// straight-line code.  Activations (the MFMA's second operand) come from LDS, this lane's operand row per tap in srow,
+// read one step ahead of the MFMAs that use them; the weights (first operand) straight from the packed L2 stream, their
+// loads running AHEAD steps in front (an L2 round trip is several steps long).
+#ifndef NZ_PERSIST_XOP
+#define NZ_PERSIST_XOP 0          // 1: a job's first weights are fetched under the epilogue of the job before it
+#endif
+#ifndef NZ_PERSIST_AHEAD
+#define NZ_PERSIST_AHEAD 6
+#endif
+constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
+// the first WAVE_AHEAD steps' weights of a column tile's stream (steps are contiguous whatever the layer's K groups)
+// (buffer loads: a wave-uniform descriptor of the column tile's stream, ONE vector register with this lane's byte offset,
+// the step's offset as a scalar -- plain global loads keep a 64-bit address pair alive per load in flight, forty registers)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_weights_rsrc(const uint32_t* wg, int chunks16) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wg), (short)0, chunks16 * 16, 0x00020000);
+}
+__device__ __forceinline__ u32x4 wave_weights_load(__amdgpu_buffer_rsrc_t rs, int voff, int st, int piece) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (st * 3 + piece) * 1024, 0));
+}
+__device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1][3], __amdgpu_buffer_rsrc_t rs, int voff) {
+#pragma unroll
+  for (int st = 0; st < WAVE_AHEAD; ++st)
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece) bq[st][piece] = wave_weights_load(rs, voff, st, piece);
+}
+template <int NTAPS, int KGT>
+__device__ __forceinline__ void wave_conv(f32x4 (&acc)[2], const float* __restrict__ net, const int (&srow)[2][NTAPS],
+                                          int off0, int cs0, int ps0, int kq, __amdgpu_buffer_rsrc_t wrs, int voff,
+                                          u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
   constexpr int STEPS = NTAPS * KGT;
-  constexpr int AHEAD = 3;
-  u32x4 bq[AHEAD + 1][NT][3];
+  constexpr int AHEAD = WAVE_AHEAD;
+  static_assert(STEPS >= AHEAD, "the prologue is always AHEAD steps");
+  u32x4 a[2][2][3];
+  auto load_a = [&](int st, u32x4 (&dst)[2][3]) {
+    const int tap = st / KGT, kg = st - tap * KGT;
 #pragma unroll
-  for (int st = 0; st < AHEAD && st < STEPS; ++st)
+    for (int rt = 0; rt < 2; ++rt) {
+      const int r = srow[rt][tap];
+      const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece) bq[st][ct][piece] = *((gptr4u)(wg + ((ct * STEPS + st) * 3 + piece) * 256));
-#pragma unroll
-  for (int tap = 0; tap < NTAPS; ++tap) {
-#pragma unroll
-    for (int kg = 0; kg < KGT; ++kg) {
-      const int st = tap * KGT + kg;
-      u32x4 a[2][3];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) {
-        const int r = srow[rt][tap];
-        const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
-#pragma unroll
-        for (int piece = 0; piece < 3; ++piece) a[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
-      }
-      if (st + AHEAD < STEPS) {
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-          for (int piece = 0; piece < 3; ++piece)
-            bq[(st + AHEAD) % (AHEAD + 1)][ct][piece] = *((gptr4u)(wg + ((ct * STEPS + st + AHEAD) * 3 + piece) * 256));
-      }
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) step16(acc[rt][ct], a[rt], bq[st % (AHEAD + 1)][ct]);
+      for (int piece = 0; piece < 3; ++piece) dst[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
     }
+  };
+  load_a(0, a[0]);
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    if (st + 1 < STEPS) load_a(st + 1, a[(st + 1) & 1]);
+    if (st + AHEAD < STEPS) {
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece)
+        bq[(st + AHEAD) % (AHEAD + 1)][piece] = wave_weights_load(wrs, voff, st + AHEAD, piece);
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
+    __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
   }
 }
 
@@ -820,25 +841,48 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
   }
 }
 
-template <int NTAPS, int KGT, int NT>
-__device__ __forceinline__ void wave_layer_part(float* __restrict__ net, const Fused16Op& op, const int (&srow)[2][NTAPS], int ct0,
-                                                int lane, int rows) {
-  f32x4 acc[2][NT];
+template <int NTAPS, int KGT>
+__device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[2], const float* __restrict__ net, const Fused16Op& op,
+                                                 const int (&srow)[2][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  wave_conv<NTAPS, KGT, NT>(acc, net, srow, op.off0, op.cs0, op.ps0, lane >> 4, op.w + (size_t)ct0 * op.w_chunks * 4 + lane * 4);
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int ct = 0; ct < NT; ++ct) wave_epilogue(acc[rt][ct], net, op, rt, ct0 + ct, lane, rows);
+  for (int rt = 0; rt < 2; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (an opaque k-quarter: the operand addresses of every step of every variant are loop-invariant arithmetic, and hoisted
+  // out of the layer loop they are 180 live registers)
+  int kq = lane >> 4;
+  asm volatile("" : "+v"(kq));
+  const int voff = lane * 16;
+  const __amdgpu_buffer_rsrc_t wrs = wave_weights_rsrc(op.w + (size_t)ct * op.w_chunks * 4, op.w_chunks);
+#if !NZ_PERSIST_XOP
+  wave_weights_prologue(bq, wrs, voff);
+#endif
+  wave_conv<NTAPS, KGT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, voff, bq);
 }
 
-// every layer of the network for the position whose input pieces sit in this wavefront's block
+// The two wavefronts of a game meet (the leader runs the tree and half of every layer, the helper the other half): each
+// posts the number of the step it has finished and waits for the other's.  LDS stores of one wavefront reach LDS in
+// order, so the partner that sees the number sees the activations stored before it.
+__device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane) {
+  ++seq;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&flags[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// every layer of the network for the position whose input pieces sit in the game's block: this wavefront takes the
+// column tiles half, half + 2, ... of each layer
+#ifdef NZ_PERSIST_STAMPS
+#define WSTAMP(slot) { if (tkn) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tkn[slot] += now - tsn; tsn = now; } }
+#else
+#define WSTAMP(slot)
+#endif
 template <bool HEX>
 __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
-                                             int H, int Wd, int lane) {
+                                             int H, int Wd, int lane, int half, int* flags, int& seq,
+                                             unsigned long long* tkn = nullptr) {
+#ifdef NZ_PERSIST_STAMPS
+  unsigned long long tsn = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int ntaps = HEX ? 7 : 9;
   int srow[2][ntaps];
 #pragma unroll
@@ -858,56 +902,64 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
   constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
   static_assert(OP_DWORDS <= 64, "one dword per lane");
   const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
-  uint32_t dvec = lane < OP_DWORDS ? ops_words[lane] : 0u;
-  for (int o = 0; o < n_ops; ++o) {
-    Fused16Op op;
-    {
-      uint32_t words[OP_DWORDS];
+  auto unpack = [](uint32_t v, Fused16Op& op) {
+    uint32_t words[OP_DWORDS];
 #pragma unroll
-      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
-      __builtin_memcpy(&op, words, sizeof(Fused16Op));
-    }
-    if (o + 1 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 1) * OP_DWORDS + lane];
+    for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(v, i);
+    __builtin_memcpy(&op, words, sizeof(Fused16Op));
+  };
+  // The weights of a (layer, column tile) job's first steps are fetched while the job before it finishes (its epilogue,
+  // the meeting of the two wavefronts): an L2 round trip at the head of every layer is most of a layer otherwise.
+  Fused16Op op, next;
+  unpack(lane < OP_DWORDS ? ops_words[lane] : 0u, op);
+  uint32_t dvec = (n_ops > 1 && lane < OP_DWORDS) ? ops_words[OP_DWORDS + lane] : 0u;
+#if NZ_PERSIST_XOP
+  u32x4 bq[WAVE_AHEAD + 1][3];
+  if (half < op.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)half * op.w_chunks * 4, op.w_chunks), lane * 16);
+#endif
+  for (int o = 0; o < n_ops; ++o) {
+    if (o + 1 < n_ops) unpack(dvec, next);
+    if (o + 2 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 2) * OP_DWORDS + lane];
     const int kgt = op.kg0;
-    for (int ct0 = 0; ct0 < op.ntiles; ct0 += 2) {
-      const bool two = ct0 + 1 < op.ntiles;
-      if (two) {
-        if (kgt == 1) wave_layer_part<ntaps, 1, 2>(net, op, srow, ct0, lane, rows);
-        else if (kgt == 2) wave_layer_part<ntaps, 2, 2>(net, op, srow, ct0, lane, rows);
-        else if (kgt == 3) wave_layer_part<ntaps, 3, 2>(net, op, srow, ct0, lane, rows);
-        else wave_layer_part<ntaps, 4, 2>(net, op, srow, ct0, lane, rows);
-      } else {
-        if (kgt == 1) wave_layer_part<ntaps, 1, 1>(net, op, srow, ct0, lane, rows);
-        else if (kgt == 2) wave_layer_part<ntaps, 2, 1>(net, op, srow, ct0, lane, rows);
-        else if (kgt == 3) wave_layer_part<ntaps, 3, 1>(net, op, srow, ct0, lane, rows);
-        else wave_layer_part<ntaps, 4, 1>(net, op, srow, ct0, lane, rows);
-      }
+    for (int ct = half; ct < op.ntiles; ct += 2) {
+      f32x4 acc[2];
+#if !NZ_PERSIST_XOP
+      u32x4 bq[WAVE_AHEAD + 1][3];
+#endif
+      if (kgt == 1) wave_layer_kloop<ntaps, 1>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3>(acc, net, op, srow, ct, lane, bq);
+      else wave_layer_kloop<ntaps, 4>(acc, net, op, srow, ct, lane, bq);
+      WSTAMP(0);
+#if NZ_PERSIST_XOP
+      // the next job's first weights: this layer's next column tile of mine, else the next layer's first
+      if (ct + 2 < op.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)(ct + 2) * op.w_chunks * 4, op.w_chunks), lane * 16);
+      else if (o + 1 < n_ops && half < next.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(next.w + (size_t)half * next.w_chunks * 4, next.w_chunks), lane * 16);
+#endif
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) wave_epilogue(acc[rt], net, op, rt, ct, lane, rows);
+      WSTAMP(1);
     }
-    scs_sync<false>();                    // the layer's stores are ordered before the next layer's reads (same wavefront)
+#if NZ_PERSIST_XOP
+    if (half >= op.ntiles && o + 1 < n_ops && half < next.ntiles)      // (a layer with no tile for this half)
+      wave_weights_prologue(bq, wave_weights_rsrc(next.w + (size_t)half * next.w_chunks * 4, next.w_chunks), lane * 16);
+#endif
+    pair_sync(flags, half, seq, lane);     // the layer is whole before either half reads it (or overwrites its source)
+    WSTAMP(2);
+    op = next;
   }
 }
 
+// the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
 template <bool HEX>
-__global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParams p, PersistArgs q) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  ScsRules& R = *reinterpret_cast<ScsRules*>(smem);
-  const int lane = lane_id();
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  {   // rules -> LDS, once per workgroup; the only workgroup barrier of the kernel
-    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_GAMES * 64) dst[i] = src[i];
-  }
-  __syncthreads();
-  const int g = blockIdx.x * PERSIST_GAMES + wave;
-  if (g >= p.n_games) return;
-  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)wave * q.wave_bytes;
+__device__ __forceinline__ void persist_leader(const SearchParams& p, const PersistArgs& q, const ScsRules& R, unsigned char* wb,
+                                               int g, int lane, int* flags, int* go) {
   ScsState& real_l = *reinterpret_cast<ScsState*>(wb);
   ScsState& sc = *reinterpret_cast<ScsState*>(wb + PERSIST_STATE_BYTES);
   uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
   int* const sidx = reinterpret_cast<int*>(wb + 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES);
   float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
+  int seq = 0, pass = 0;
   if (p.real[g].terminal) return;
   int sims_left = p.sims_left[g];
   if (sims_left <= 0) return;
@@ -937,6 +989,13 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
   scs_sync<false>();
   unsigned long long n_sim = 0, n_exp = 0;
   bool failed = false;
+#ifdef NZ_PERSIST_STAMPS   // diagnostic build: where a game's time goes (nz_scs_search_persist_ticks)
+  unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
+  const unsigned long long t_begin = ts;
+#define PSTAMP(slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tk[slot] += now - ts; ts = now; }
+#else
+#define PSTAMP(slot)
+#endif
 
   while (sims_left > 0) {
     {   // scratch_game = game.shallow_clone()
@@ -945,6 +1004,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
       for (int i = lane; i < (int)(sizeof(ScsState) / 4); i += 64) dst[i] = src[i];
       scs_sync<false>();
     }
+    PSTAMP(0);                                  // clone
     int node = root, plen = 1;
     int my_path = root;                         // lane i holds path[i] (levels past 63 go to memory)
     bool bad = false;
@@ -993,6 +1053,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
       break;
     }
     scs_sync<false>();
+    PSTAMP(1);                                  // descent: scores, argmax, rule steps
     const int to_play = sc.player, term = sc.terminal;
     double v;
     if (term) {                                 // Explorer.py:140-142: the stored terminal value, no network
@@ -1029,6 +1090,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
         failed = true;
         break;
       }
+      PSTAMP(2);                                // legal mask + list
       // the leaf's planes (generate_network_input, SCS_Game.py:1507): float32 rows over the trunk buffers' space, split
       // into the input pieces, then that space is zeros again (the buffers' rows of zeros, channels no layer writes)
       float* const stage = net + q.stage_off;
@@ -1060,7 +1122,16 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
       scs_sync<false>();
       for (int i = lane * 4; i < q.stage_floats; i += 256) *reinterpret_cast<f32x4*>(stage + i) = f32x4{0.f, 0.f, 0.f, 0.f};
       scs_sync<false>();
-      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane);
+      PSTAMP(3);                                // planes, split, staging cleared
+      ++pass;                                   // the helper wavefront starts on its half of the layers
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(go, pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef NZ_PERSIST_STAMPS
+      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq, tk + 10);
+#else
+      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
+#endif
+      PSTAMP(4);                                // network
       // softmax over ALL logits (Explorer.py:158-160) and value = tanh(mean of the value plane) (blocks.py:82-84)
       float* const pol = net + pol_off;
       float mx = -INFINITY;
@@ -1098,6 +1169,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
       v = (double)value;
       (void)planes;
       scs_sync<false>();
+      PSTAMP(5);                                // softmax + value
       if (rec >= 0) {
         if (rec_n < q.rec_cap) {
           const size_t at = (size_t)rec * q.rec_cap + rec_n;
@@ -1146,6 +1218,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
       }
       base += k;
       ++n_exp;
+      PSTAMP(6);                                // expansion
     }
     // backup (Explorer.py:132-135): the same value to every node of the path, root included
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -1162,7 +1235,19 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     --sims_left;
     ++n_sim;
+    PSTAMP(7);                                  // backup
   }
+#ifdef NZ_PERSIST_STAMPS
+  if (lane == 0) {
+    tk[8] = __builtin_amdgcn_s_memtime() - t_begin;        // the game's whole move
+    for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)&p.counters[2 + i], tk[i]);
+    for (int i = 6; i < 9; ++i) atomicAdd((unsigned long long*)&p.counters[5 + i], tk[i]);
+    atomicMax((unsigned long long*)&p.counters[14], tk[8]);  // the slowest (game, move) of the round
+    // inside the network (the leader's half): K loops, epilogues, waiting for the helper -- in the cache counters' words
+    // (a diagnostic build runs without the cache)
+    for (int i = 0; i < 3; ++i) atomicAdd((unsigned long long*)&p.counters[8 + i], tk[10 + i]);
+  }
+#endif
   if (lane == 0) {
     p.sims_left[g] = failed ? sims_left : 0;
     p.pending[g] = -1;
@@ -1170,6 +1255,54 @@ __global__ __launch_bounds__(PERSIST_GAMES * 64) void persist_kernel(SearchParam
     if (rec >= 0) q.rec_count[rec] = rec_n;
     if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], n_sim);
     if (n_exp) atomicAdd((unsigned long long*)&p.counters[1], n_exp);
+  }
+}
+
+template <bool HEX>
+__global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p, PersistArgs q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ScsRules& R = *reinterpret_cast<ScsRules*>(smem);
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // wavefronts 0..3 lead games 0..3; wavefront 4 + i helps game (i + 3) & 3, so that every SIMD hosts one leader and
+  // one helper of ANOTHER game (a helper sleeps through its game's tree phases)
+  const bool leader = wave < PERSIST_GAMES;
+  const int slot = leader ? wave : ((wave - PERSIST_GAMES + 3) & (PERSIST_GAMES - 1));
+  {   // rules -> LDS, once per workgroup, and the games' flag words; the only workgroup barrier of the kernel
+    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+    for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_THREADS) dst[i] = src[i];
+    if (threadIdx.x < PERSIST_GAMES * 4)
+      reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+  }
+  __syncthreads();
+  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
+  int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
+  int* const go = flags + 2;
+  const int g = blockIdx.x * PERSIST_GAMES + slot;
+  if (leader) {
+    if (g < p.n_games) persist_leader<HEX>(p, q, R, wb, g, lane, flags, go);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+  // helper: half of every layer of every network pass of its game, asleep in between
+  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
+  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
+#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
+  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+#undef PHDR
+  int seq = 0, pass = 0;
+  for (;;) {
+    int gv;
+    while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(8);
+    if (gv == PERSIST_EXIT) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    pass = gv;
+    wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 1, flags, seq);
   }
 }
 
@@ -1836,11 +1969,20 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     if (persist) {                               // the whole move's search of every game: one launch
       if (h->persist_used == 2)
-        hipLaunchKernelGGL(persist_kernel<true>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
+        hipLaunchKernelGGL(persist_kernel<true>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       else
-        hipLaunchKernelGGL(persist_kernel<false>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
+        hipLaunchKernelGGL(persist_kernel<false>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       S_HIP(h, hipGetLastError());
       ++h->waves;
+      static const bool move_times = getenv("NZ_SCS_MOVE_TIMES") != nullptr;     // experiment: the duration of every move's launch
+      if (move_times) {
+        int live = 0;
+        for (int g = 0; g < G; ++g) live += status[(size_t)g * 7 + 4] == 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        S_HIP(h, hipStreamSynchronize(s));
+        fprintf(stderr, "move %lld: %d live games, %.3f ms\n", (long long)move, live,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
       st = nz_scs_search_end_move(h, h->uniforms, stream);
       if (st != NZ_OK) return st;
       continue;
@@ -2051,6 +2193,22 @@ nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* cou
   if (digests_host) S_HIP(h, hipMemcpy(digests_host, h->pq.rec_digest + 2 * at, n * 16, hipMemcpyDeviceToHost));
   if (probs_host) S_HIP(h, hipMemcpy(probs_host, h->pq.rec_probs + at * A, n * A * 4, hipMemcpyDeviceToHost));
   if (values_host) S_HIP(h, hipMemcpy(values_host, h->pq.rec_value + at, n * 4, hipMemcpyDeviceToHost));
+  return NZ_OK;
+}
+
+// Diagnostic (library built with -DNZ_PERSIST_STAMPS; zeros otherwise): shader ticks of the persistent kernel summed
+// over all games and moves since the last reset -- out10: clone, descent, legal mask + list, planes + split, network,
+// softmax + value, expansion, backup, whole moves (sum over games), the slowest single (game, move).
+nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out10_host) {   // (13 values)
+  if (!h || !out10_host) return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  int64_t c[16];
+  S_HIP(h, hipMemcpy(c, h->p.counters, sizeof(c), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 6; ++i) out10_host[i] = c[2 + i];
+  for (int i = 6; i < 9; ++i) out10_host[i] = c[5 + i];
+  out10_host[9] = c[14];
+  for (int i = 0; i < 3; ++i) out10_host[10 + i] = c[8 + i];
   return NZ_OK;
 }
 

@@ -349,6 +349,14 @@ class ScsSelfPlay:
         self._check(lib.nz_scs_search_persistent(self._h, int(enable), byref(used)))
         return bool(used.value)
 
+    def persist_ticks(self):
+        """Diagnostic build (-DNZ_PERSIST_STAMPS) only: shader ticks per phase of the persistent kernel."""
+        out = (ctypes.c_int64 * 13)()
+        self._check(lib.nz_scs_search_persist_ticks(self._h, out))
+        keys = ("clone", "descent", "mask_list", "planes_split", "network", "softmax_value", "expansion", "backup",
+                "moves_total", "slowest_game_move", "net_k_loops", "net_epilogues", "net_pair_waits")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def record(self, games, capacity):
         """Test hook of the persistent route: keep the leaf evaluations of `games` (indices), up to `capacity` each,
         in the order each game's search consumes them (nz_scs_search_record); games = [] stops recording."""
