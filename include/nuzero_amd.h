@@ -456,6 +456,9 @@ nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* us
  * expansion, backup, whole moves, the slowest single (game, move); inside the network (leader's half): K loops,
  * epilogues, waits for the helper.  13 values. */
 nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out13_host);
+/* Diagnostic: the persistent route's network alone -- `blocks` workgroups of four (leader, helper) wavefront pairs each
+ * run `iters` passes on an all-zero input; ticks_host[blocks * 4] = shader ticks per pass. */
+nz_status nz_scs_netbench(nz_boardnet* net, int32_t blocks, int32_t iters, uint64_t* ticks_host);
 nz_status nz_scs_search_record(nz_scs_search* h, const int32_t* games_host, int32_t n, int32_t capacity);
 nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* count, uint64_t* digests_host,
                                     float* probs_host, float* values_host);

@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nuzero_amd.h"
@@ -741,7 +742,7 @@ __device__ __forceinline__ void image_hash_wave(const float* stage, int inp, int
 #define NZ_PERSIST_XOP 0          // 1: a job's first weights are fetched under the epilogue of the job before it
 #endif
 #ifndef NZ_PERSIST_AHEAD
-#define NZ_PERSIST_AHEAD 6
+#define NZ_PERSIST_AHEAD 3
 #endif
 constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
 // the first WAVE_AHEAD steps' weights of a column tile's stream (steps are contiguous whatever the layer's K groups)
@@ -751,7 +752,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_weights_rsrc(const uint32
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wg), (short)0, chunks16 * 16, 0x00020000);
 }
 __device__ __forceinline__ u32x4 wave_weights_load(__amdgpu_buffer_rsrc_t rs, int voff, int st, int piece) {
+#ifdef NZ_ABL_PERSIST_NOB      // timing experiment: no weight stream (results wrong)
+  return u32x4{(uint32_t)voff, (uint32_t)st, (uint32_t)piece, 0u};
+#else
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (st * 3 + piece) * 1024, 0));
+#endif
 }
 __device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1][3], __amdgpu_buffer_rsrc_t rs, int voff) {
 #pragma unroll
@@ -774,7 +779,13 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[2], const float* __restri
       const int r = srow[rt][tap];
       const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
 #pragma unroll
-      for (int piece = 0; piece < 3; ++piece) dst[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
+      for (int piece = 0; piece < 3; ++piece) {
+#ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
+        dst[rt][piece] = u32x4{(uint32_t)a0, (uint32_t)piece, 0u, 0u};
+#else
+        dst[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
+#endif
+      }
     }
   };
   load_a(0, a[0]);
@@ -1013,15 +1024,23 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       const SNode r0 = nodes[root];
       par_visit = r0.visit; par_base = r0.child_base; par_k = r0.n_children; par_to_play = r0.to_play;
     }
+    // A level's children (its first 64) and its two table entries are fetched BEFORE the rule step that leads to it:
+    // the round trip to L2 runs under the step's serial code instead of after it.
+    SNode cnext;
+    double sq = 0.0, cb = 0.0;
+    auto fetch_level = [&]() {
+      if (lane < par_k) cnext = nodes[par_base + lane];
+      if (par_visit < p.tab_len) { sq = p.sqrt_tab[par_visit]; cb = p.bias_tab[par_visit]; }
+    };
+    fetch_level();
     while (par_k > 0) {
       if (par_visit >= p.tab_len || plen >= p.max_path) { bad = true; break; }
-      const double sq = p.sqrt_tab[par_visit], cb = p.bias_tab[par_visit];
       const bool negate = par_to_play == p.negate_player;
       double score = -INFINITY;
       int key = -1;
       int b_visit = 0, b_base = 0, b_k = 0, b_to_play = 0;
       for (int j = lane; j < par_k; j += 64) {
-        const SNode c = nodes[par_base + j];
+        const SNode c = j < 64 ? cnext : nodes[par_base + j];
         const double scv = child_score(p, c, sq, cb, negate);
         const int ky = ((int)c.action << 8) | j;
         if (scv > score || (scv == score && ky > key)) {
@@ -1042,6 +1061,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       par_base = __builtin_amdgcn_readlane(b_base, wl);
       par_k = __builtin_amdgcn_readlane(b_k, wl);
       par_to_play = __builtin_amdgcn_readlane(b_to_play, wl);
+      if (par_k > 0) fetch_level();
       if (plen < 64) { if (lane == plen) my_path = node; }
       else if (lane == 0) path[plen] = node;
       scs_step_wave<false>(R, sc, key >> 8, lane);
@@ -1132,27 +1152,35 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
 #endif
       PSTAMP(4);                                // network
+
       // softmax over ALL logits (Explorer.py:158-160) and value = tanh(mean of the value plane) (blocks.py:82-84)
       float* const pol = net + pol_off;
+      // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
+      const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
       float mx = -INFINITY;
-      for (int i = lane; i < A; i += 64) {
-        const int plane = i / hw, cell = i - plane * hw;
+      for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
         mx = fmaxf(mx, pol[cell * pp + plane]);
+        cell += dcell; plane += dplane;
+        if (cell >= hw) { cell -= hw; ++plane; }
       }
       for (int w = 32; w; w >>= 1) mx = fmaxf(mx, __shfl_xor(mx, w, 64));
       // the sum in fused16_net_kernel's order for a workgroup of up to four positions (four wavefronts per position, each
       // lane adding every 256th entry, a butterfly per wavefront, the four partial sums added in turn), so that a game
       // plays the same moves on either route
       float part[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int i0 = 0; i0 < A; i0 += 256) {
+      {
+        int cell = cell0, plane = plane0;
+        for (int i0 = 0; i0 < A; i0 += 256) {
 #pragma unroll
-        for (int sub = 0; sub < 4; ++sub) {
-          const int i = i0 + sub * 64 + lane;
-          if (i < A) {
-            const int plane = i / hw, cell = i - plane * hw;
-            const float e = expf(pol[cell * pp + plane] - mx);
-            pol[cell * pp + plane] = e;
-            part[sub] += e;
+          for (int sub = 0; sub < 4; ++sub) {
+            const int i = i0 + sub * 64 + lane;
+            if (i < A) {
+              const float e = expf(pol[cell * pp + plane] - mx);
+              pol[cell * pp + plane] = e;
+              part[sub] += e;
+            }
+            cell += dcell; plane += dplane;
+            if (cell >= hw) { cell -= hw; ++plane; }
           }
         }
       }
@@ -1304,6 +1332,37 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
     pass = gv;
     wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 1, flags, seq);
   }
+}
+
+// Diagnostic: the network part of persist_kernel alone -- every game slot of every workgroup runs `iters` passes on an
+// all-zero input (leader + helper exactly as in the search), out[block * PERSIST_GAMES + slot] = shader ticks per pass.
+template <bool HEX>
+__global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q, int iters, unsigned long long* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool leader = wave < PERSIST_GAMES;
+  const int slot = leader ? wave : ((wave - PERSIST_GAMES + 3) & (PERSIST_GAMES - 1));
+  if (threadIdx.x < PERSIST_GAMES * 4)
+    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+  __syncthreads();
+  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
+  int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
+  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
+  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
+#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
+  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+#undef PHDR
+  if (leader)
+    for (int i = lane * 4; i < q.net_floats; i += 256) *reinterpret_cast<f32x4*>(net + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  int seq = 0;
+  pair_sync(flags, leader ? 0 : 1, seq, lane);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)iters;
 }
 
 __global__ void search_status_kernel(SearchParams p, int32_t* out) {
@@ -1943,18 +2002,29 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     if (h->cfg.training) {
       std::fill(noise.begin(), noise.end(), 0.0);
       std::fill(uni.begin(), uni.end(), 0.0);
-      for (int g = 0; g < G; ++g) {
-        if (status[(size_t)g * 7 + 4]) continue;
-        nz_rng* r = rngs[g];
-        nz_rng_gamma(r, h->cfg.root_dist_alpha, h->cfg.root_dist_beta, nchild[g], &noise[(size_t)g * MAXC]);
-        double* u = &uni[(size_t)g * 3];
-        if (status[(size_t)g * 7 + 6] < h->cfg.number_of_softmax_moves) {
-          u[2] = nz_rng_double(r);
-        } else {
-          u[0] = nz_rng_double(r);
-          u[1] = nz_rng_double(r);
-          if (u[0] < h->cfg.epsilon_softmax_exploration || u[1] < h->cfg.epsilon_random_exploration) u[2] = nz_rng_double(r);
+      // (every game has its own stream: the draws of different games run on host threads side by side)
+      auto draw = [&](int g0, int g1) {
+        for (int g = g0; g < g1; ++g) {
+          if (status[(size_t)g * 7 + 4]) continue;
+          nz_rng* r = rngs[g];
+          nz_rng_gamma(r, h->cfg.root_dist_alpha, h->cfg.root_dist_beta, nchild[g], &noise[(size_t)g * MAXC]);
+          double* u = &uni[(size_t)g * 3];
+          if (status[(size_t)g * 7 + 6] < h->cfg.number_of_softmax_moves) {
+            u[2] = nz_rng_double(r);
+          } else {
+            u[0] = nz_rng_double(r);
+            u[1] = nz_rng_double(r);
+            if (u[0] < h->cfg.epsilon_softmax_exploration || u[1] < h->cfg.epsilon_random_exploration) u[2] = nz_rng_double(r);
+          }
         }
+      };
+      const int n_thr = G >= 256 ? std::min<int>(8, std::max<unsigned>(1u, std::thread::hardware_concurrency())) : 1;
+      if (n_thr <= 1) {
+        draw(0, G);
+      } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_thr; ++t) pool.emplace_back(draw, (int)((int64_t)G * t / n_thr), (int)((int64_t)G * (t + 1) / n_thr));
+        for (std::thread& t : pool) t.join();
       }
       S_HIP(h, hipMemcpyAsync(h->noise, noise.data(), noise.size() * sizeof(double), hipMemcpyHostToDevice, s));
       S_HIP(h, hipMemcpyAsync(h->uniforms, uni.data(), uni.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -2209,6 +2279,33 @@ nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out10_host) {  
   for (int i = 6; i < 9; ++i) out10_host[i] = c[5 + i];
   out10_host[9] = c[14];
   for (int i = 0; i < 3; ++i) out10_host[10 + i] = c[8 + i];
+  return NZ_OK;
+}
+
+// Diagnostic: shader ticks of one per-wavefront-pair network pass (netbench_kernel), `blocks` workgroups of four game
+// slots each running `iters` passes; ticks_host[blocks * 4].
+nz_status nz_scs_netbench(nz_boardnet* net, int32_t blocks, int32_t iters, uint64_t* ticks_host) {
+  if (!net || blocks <= 0 || iters <= 0 || !ticks_host) return NZ_ERR_ARG;
+  nz::WaveNet wn{};
+  std::string why;
+  if (!nz::boardnet_wave_program(net, &wn, &why)) return sfail(nullptr, NZ_ERR_STATE, "%s", why.c_str());
+  PersistArgs q{};
+  q.prog = wn.prog; q.net_floats = wn.lds_floats; q.stage_off = wn.stage_off; q.stage_floats = wn.stage_floats;
+  q.inp = wn.inp; q.in_channels = wn.in_channels;
+  q.wave_bytes = PERSIST_GAME_BYTES + (wn.lds_floats * 4 + 15) / 16 * 16;
+  const size_t lds = (size_t)PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
+  unsigned long long* out = nullptr;
+  S_HIP(nullptr, hipMalloc((void**)&out, (size_t)blocks * PERSIST_GAMES * 8));
+  hipError_t e = wn.hex ? hipFuncSetAttribute((const void*)netbench_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                        : hipFuncSetAttribute((const void*)netbench_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) {
+    if (wn.hex) hipLaunchKernelGGL(netbench_kernel<true>, dim3(blocks), dim3(PERSIST_THREADS), lds, nullptr, q, iters, out);
+    else hipLaunchKernelGGL(netbench_kernel<false>, dim3(blocks), dim3(PERSIST_THREADS), lds, nullptr, q, iters, out);
+    e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(ticks_host, out, (size_t)blocks * PERSIST_GAMES * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(out);
+  if (e != hipSuccess) return sfail(nullptr, NZ_ERR_HIP, "netbench: %s", hipGetErrorString(e));
   return NZ_OK;
 }
 
