@@ -140,6 +140,7 @@ def scs_config4(device, games_per_tree=1):
     sp = ScsSelfPlay(cfg, search, G, device=device)
     sp.play_native(net, range(G), max_moves=2)            # warm-up: first launches, allocations
     torch.cuda.synchronize()
+    sp.persist_profile(1)                                 # HIP events around the persistent kernel, on its stream
     t0 = time.perf_counter()
     r = sp.play_round(net, range(10 ** 6, 10 ** 6 + N))
     torch.cuda.synchronize()
@@ -147,8 +148,26 @@ def scs_config4(device, games_per_tree=1):
     out = {"value": N / dt, "unit": "games/s", "expansions_per_s": r["expansions"] / dt,
            "simulations_per_s": r["simulations"] / dt, "seconds": dt, "waves": r["waves"], "games_per_round": N,
            "net_tflops_algorithmic": r["expansions"] * net.flops_per_position / dt / 1e12,
+           "route": "persistent kernel (one launch per move: every game's whole search, network included)"
+                    if sp.persistent() else "wave by wave (wave_kernel + one network launch per simulation wave)",
            "workload": "SCS mirrored 5x5 map (stack 2, 86 planes, 525 actions), ConvNet(32 filters, 8 layers, 3x3 square "
                        "convs), 200 sims/move, 1024 concurrent self-play games, a1 search config, 1 GPU"}
+    pp = sp.persist_profile()
+    if sp.persistent() and pp["launches"]:
+        # the dominant kernel of this workload against the matrix pipes it issues on: bf16 MFMA FLOPs executed (16x16x32:
+        # 16,384 each; six split terms per float32 product; 25 cells in two 16-row tiles) over its HIP-event time
+        executed = r["expansions"] * pp["mfma_per_position"] * 16384 / (pp["ms"] * 1e-3) / 1e12
+        out["roofline_scs"] = {"bound": "mfma", "kernel": "persist_kernel (SCS tree search + rules + ConvNet forward per wavefront pair)",
+                               "achieved": executed, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": executed / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                               "avg_launch_us": pp["ms"] * 1e3 / pp["launches"], "launches": pp["launches"],
+                               "kernel_seconds": pp["ms"] * 1e-3,
+                               "positions_per_launch": r["expansions"] / pp["launches"],
+                               "mfma_per_position": pp["mfma_per_position"],
+                               "algorithmic_f32": {"tflops": r["expansions"] * pp["flops_per_position"] / (pp["ms"] * 1e-3) / 1e12,
+                                                   "flops_per_position": pp["flops_per_position"]},
+                               "note": "latency-bound, not throughput-bound: 1024 games are 4 per CU, one simulation in "
+                                       "flight per tree (Explorer.py:49-61), so a game's network pass runs on two wavefronts"}
     sp.close()
     net.close()
     return out

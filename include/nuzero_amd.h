@@ -447,6 +447,23 @@ nz_status nz_scs_search_waves(const nz_scs_search* h, int64_t* waves);
  * enable: 1 require it (a play fails where it is not available), 0 never, -1 the default (use it where available).
  * *used (may be NULL): whether the last play ran on it. */
 nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* used);
+/* Every game on its OWN map: the reference builds a new game object per game (Training/Gamer.py:52) and a "Randomized"
+ * config draws terrain and victory points from numpy's global stream when that object is built (SCS_Game.py:1678-1738;
+ * what most of the reference's SCS presets train on, Run.py:115).  Host arrays for n games (n >= the games of a round;
+ * game i of a round reads row i whichever slot plays it): terrain float32 [n][tiles][3] (attack modifier, defense
+ * modifier, cost), vp int32 [n][n_vp0 + n_vp1][2] (row, column), the counts as in the description passed to
+ * nz_scs_search_create (its own map is then only a template: bound the limits with the cheapest terrain).  mt_keys
+ * uint32 [n][624] + mt_pos int32 [n] (both or neither): the numpy RandomState state each game's stream goes on from --
+ * where the map's draws left it, so that one stream serves map and search as in `np.random.seed(s); SCS_Game(cfg); play`;
+ * the `seeds` of the play calls are then ignored (may be NULL).  n = 0: back to the description's one map.  Resets. */
+nz_status nz_scs_search_set_games(nz_scs_search* h, int64_t n, const float* terrain_host, const int32_t* vp_host,
+                                  const uint32_t* mt_keys_host, const int32_t* mt_pos_host);
+/* As above for the rule operators: every game of the batch on its own map (NULL terrain: the description's).  Resets. */
+nz_status nz_scs_set_maps(nz_scs* h, const float* terrain_host, const int32_t* vp_host, void* stream);
+/* HIP-event timing of the persistent kernel, on the stream it is launched on.  enable: 1 on (sums zeroed), 0 off, -1 leave.
+ * out4_host (may be NULL): milliseconds summed over launches, launches, v_mfma_f32_16x16x32_bf16 instructions issued
+ * per evaluated position, algorithmic float32 FLOPs per position. */
+nz_status nz_scs_search_persist_profile(nz_scs_search* h, int32_t enable, double* out4_host);
 /* Test hook of the persistent route: keep the leaf evaluations of n games (games_host: indices), up to `capacity`
  * each, in the order the game's search consumed them; n = 0 stops.  nz_scs_search_record_read (host pointers, any of the
  * three arrays may be NULL): *count evaluations consumed, digests uint64 [.][2] (a 128-bit mix of the leaf's float32
@@ -467,6 +484,9 @@ nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* cou
  * Replaces the reference's use of the global np.random stream
  * (Explorer.py:77-78,89,199,208). */
 nz_rng* nz_rng_create(uint32_t seed);
+/* a stream that goes on where a numpy RandomState stands (RandomState.get_state(): key[624], pos, has_gauss, cached_gaussian) */
+nz_rng* nz_rng_create_state(const uint32_t* key624, int32_t pos, int32_t has_gauss, double cached_gaussian);
+nz_rng* nz_rng_clone(const nz_rng* r);
 void nz_rng_destroy(nz_rng* r);
 void nz_rng_seed(nz_rng* r, uint32_t seed);
 uint32_t nz_rng_u32(nz_rng* r);

@@ -132,8 +132,11 @@ SIGNATURES = {
     "nz_scs_search_cache": (c_int32, [c_void_p, c_int64]),
     "nz_scs_search_cache_stats": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_scs_search_limits": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
+    "nz_scs_search_set_games": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nz_scs_set_maps": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_persistent": (c_int32, [c_void_p, c_int32, POINTER(c_int32)]),
     "nz_scs_search_persist_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),
+    "nz_scs_search_persist_profile": (c_int32, [c_void_p, c_int32, POINTER(ctypes.c_double)]),
     "nz_scs_netbench": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "nz_scs_search_record": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
     "nz_scs_search_record_read": (c_int32, [c_void_p, c_int32, POINTER(c_int32), c_void_p, c_void_p, c_void_p]),
@@ -150,6 +153,8 @@ SIGNATURES = {
                                            c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nz_loss_last_error": (c_char_p, []),
     "nz_rng_create": (c_void_p, [c_uint32]),
+    "nz_rng_create_state": (c_void_p, [c_void_p, c_int32, c_int32, c_double]),
+    "nz_rng_clone": (c_void_p, [c_void_p]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),
     "nz_rng_u32": (c_uint32, [c_void_p]),

@@ -1803,6 +1803,8 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
   w.inp = h->inp; w.in_channels = nd.in_channels;
   w.hw = h->hw; w.rows = h->rows; w.cols = h->cols; w.planes = nd.policy_channels; w.hex = nd.hex ? 1 : 0; w.n_ops = n_ops;
   w.flops = h->flops;
+  w.mfmas = 0;
+  for (int i = 0; i < n_ops; ++i) w.mfmas += (int64_t)2 * pg.ops[i].ntiles * ntaps * pg.ops[i].kg0 * 6;
   h->wave_state = 1;
   *out = w;
   return true;

@@ -18,6 +18,7 @@ struct WaveNet {
   int32_t inp, in_channels;       // padded / real input planes
   int32_t hw, rows, cols, planes, hex, n_ops;
   int64_t flops;                  // algorithmic float32 FLOPs per position
+  int64_t mfmas;                  // v_mfma_f32_16x16x32_bf16 issued per position (two row tiles, six split terms, padding included)
 };
 
 // false (with the reason): this network has no per-wavefront form (architecture, board size, widths, LDS)

@@ -125,6 +125,19 @@ double std_gamma(nz_rng* r, double shape) {
 
 extern "C" {
 
+// a stream that continues where a numpy RandomState stands (RandomState.get_state(): key, pos, has_gauss, cached_gaussian)
+nz_rng* nz_rng_create_state(const uint32_t* key624, int32_t pos, int32_t has_gauss, double cached_gaussian) {
+  if (!key624 || pos < 0 || pos > 624) return nullptr;
+  nz_rng* r = new nz_rng;
+  for (int i = 0; i < 624; ++i) r->key[i] = key624[i];
+  r->pos = pos;
+  r->has_gauss = has_gauss ? 1 : 0;
+  r->gauss = cached_gaussian;
+  return r;
+}
+
+nz_rng* nz_rng_clone(const nz_rng* r) { return r ? new nz_rng(*r) : nullptr; }
+
 nz_rng* nz_rng_create(uint32_t seed) {
   nz_rng* r = new nz_rng;
   seed_state(r, seed);

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/nuzero_amd.h"
 #include "scs_dev.hpp"
@@ -14,7 +15,8 @@ using namespace nz;
 struct nz_scs {
   int device = 0, n_games = 0;
   ScsRules host_rules;
-  ScsRules* rules = nullptr;
+  ScsRules* rules = nullptr;                 // one description, or one per game (nz_scs_set_maps)
+  int rules_stride = 0;                      // 0: every game reads rules[0]; 1: game g reads rules[g]
   ScsState* states = nullptr;
   std::string error;
 };
@@ -22,27 +24,31 @@ struct nz_scs {
 namespace {
 thread_local std::string g_scs_error;
 
-__global__ void scs_reset_kernel(const ScsRules* r, ScsState* st, int n) {
+// (`rs`: 0 = one description for every game, 1 = game g has its own, with its own map)
+__global__ void scs_reset_kernel(const ScsRules* r, int rs, ScsState* st, int n) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < n) Scs(*r, st[g]).reset();
+  if (g < n) Scs(r[(size_t)g * rs], st[g]).reset();
 }
-__global__ void scs_step_kernel(const ScsRules* r, ScsState* st, const int32_t* actions, int n) {
+__global__ void scs_step_kernel(const ScsRules* r, int rs, ScsState* st, const int32_t* actions, int n) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const int a = actions[g];
-  if (a >= 0 && !st[g].terminal) Scs(*r, st[g]).step(a);
+  if (a >= 0 && !st[g].terminal) Scs(r[(size_t)g * rs], st[g]).step(a);
 }
-__global__ void scs_mask_kernel(const ScsRules* r, ScsState* st, int8_t* mask, int n) {
+__global__ void scs_mask_kernel(const ScsRules* r0, int rs, ScsState* st, int8_t* mask, int n) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
+  const ScsRules* r = r0 + (size_t)g * rs;
   const int na = r->planes * r->tiles;
   int8_t* m = mask + (size_t)g * na;
   for (int i = 0; i < na; ++i) m[i] = 0;
   if (!st[g].terminal) Scs(*r, st[g]).for_each_legal([&](int a) { m[a] = 1; });
 }
-__global__ void scs_image_kernel(const ScsRules* r, ScsState* st, float* img, int n) {
+__global__ void scs_image_kernel(const ScsRules* r0, int rs, ScsState* st, float* img, int n) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < n) Scs(*r, st[g]).state_image(img + (size_t)g * r->channels * r->tiles);
+  if (g >= n) return;
+  const ScsRules* r = r0 + (size_t)g * rs;
+  Scs(*r, st[g]).state_image(img + (size_t)g * r->channels * r->tiles);
 }
 __global__ void scs_status_kernel(const ScsState* st, int32_t* out, int n) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,7 +135,45 @@ bool nz::scs_fill_rules(const nz_scs_desc* d, ScsRules* out, std::string* err) {
   return true;
 }
 
+// A game's own map over a description: terrain [tiles][3] (attack modifier, defense modifier, cost) and the victory
+// points [n_vp[0] + n_vp[1]][2] (row, column), the counts as in the description.
+void nz::scs_apply_map(ScsRules* r, const float* terrain, const int32_t* vp) {
+  for (int t = 0; t < r->tiles; ++t) {
+    r->attack_mod[t] = terrain[t * 3 + 0];
+    r->defense_mod[t] = terrain[t * 3 + 1];
+    r->cost[t] = (int32_t)terrain[t * 3 + 2];
+    for (int k = 0; k < 3; ++k) r->terrain_f[t][k] = terrain[t * 3 + k];
+  }
+  for (int p = 0, k = 0; p < 2; ++p)
+    for (int i = 0; i < r->n_vp[p]; ++i, ++k) r->vp[p][i] = (int8_t)(vp[k * 2] * r->cols + vp[k * 2 + 1]);
+}
+
 extern "C" {
+
+// Every game of the batch on its own map (host arrays: terrain float32 [G][tiles][3], vp int32 [G][n_vp0 + n_vp1][2]);
+// the games are reset.  NULL terrain: back to the description's one map.
+nz_status nz_scs_set_maps(nz_scs* h, const float* terrain_host, const int32_t* vp_host, void* stream) {
+  if (!h || (terrain_host && !vp_host)) return NZ_ERR_ARG;
+  SCS_HIP(h, hipSetDevice(h->device));
+  SCS_HIP(h, hipDeviceSynchronize());
+  const int want = terrain_host ? h->n_games : 1;
+  std::vector<ScsRules> rows((size_t)want, h->host_rules);
+  if (terrain_host) {
+    const ScsRules& b = h->host_rules;
+    const int T = b.tiles, nv = b.n_vp[0] + b.n_vp[1];
+    for (int g = 0; g < want; ++g) nz::scs_apply_map(&rows[g], terrain_host + (size_t)g * T * 3, vp_host + (size_t)g * nv * 2);
+  }
+  ScsRules* dev = nullptr;
+  SCS_HIP(h, hipMalloc((void**)&dev, rows.size() * sizeof(ScsRules)));
+  if (hipMemcpy(dev, rows.data(), rows.size() * sizeof(ScsRules), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(dev);
+    return scs_fail(h, NZ_ERR_HIP, "upload failed");
+  }
+  (void)hipFree(h->rules);
+  h->rules = dev;
+  h->rules_stride = terrain_host ? 1 : 0;
+  return nz_scs_reset(h, stream);
+}
 
 const char* nz_scs_last_error(const nz_scs* h) { return h ? h->error.c_str() : g_scs_error.c_str(); }
 
@@ -155,7 +199,7 @@ nz_status nz_scs_create(nz_scs** out, const nz_scs_desc* d, int32_t n_games, int
     nz_scs_destroy(h);
     return scs_fail(nullptr, NZ_ERR_HIP, "device allocation failed");
   }
-  hipLaunchKernelGGL(scs_reset_kernel, dim3(blocks(n_games)), dim3(128), 0, nullptr, h->rules, h->states, n_games);
+  hipLaunchKernelGGL(scs_reset_kernel, dim3(blocks(n_games)), dim3(128), 0, nullptr, h->rules, 0, h->states, n_games);
   if (hipDeviceSynchronize() != hipSuccess) {
     nz_scs_destroy(h);
     return scs_fail(nullptr, NZ_ERR_HIP, "reset kernel failed");
@@ -184,7 +228,7 @@ nz_status nz_scs_dims(const nz_scs* h, int32_t* planes, int32_t* rows, int32_t* 
 nz_status nz_scs_reset(nz_scs* h, void* stream) {
   if (!h) return NZ_ERR_ARG;
   SCS_HIP(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(scs_reset_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->states,
+  hipLaunchKernelGGL(scs_reset_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->rules_stride, h->states,
                      h->n_games);
   SCS_HIP(h, hipGetLastError());
   return NZ_OK;
@@ -193,7 +237,7 @@ nz_status nz_scs_reset(nz_scs* h, void* stream) {
 nz_status nz_scs_step(nz_scs* h, const int32_t* actions_dev, void* stream) {
   if (!h || !actions_dev) return NZ_ERR_ARG;
   SCS_HIP(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(scs_step_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->states,
+  hipLaunchKernelGGL(scs_step_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->rules_stride, h->states,
                      actions_dev, h->n_games);
   SCS_HIP(h, hipGetLastError());
   return NZ_OK;
@@ -202,7 +246,7 @@ nz_status nz_scs_step(nz_scs* h, const int32_t* actions_dev, void* stream) {
 nz_status nz_scs_legal_mask(nz_scs* h, int8_t* mask_dev, void* stream) {
   if (!h || !mask_dev) return NZ_ERR_ARG;
   SCS_HIP(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(scs_mask_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->states,
+  hipLaunchKernelGGL(scs_mask_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->rules_stride, h->states,
                      mask_dev, h->n_games);
   SCS_HIP(h, hipGetLastError());
   return NZ_OK;
@@ -211,7 +255,7 @@ nz_status nz_scs_legal_mask(nz_scs* h, int8_t* mask_dev, void* stream) {
 nz_status nz_scs_state_image(nz_scs* h, float* image_dev, void* stream) {
   if (!h || !image_dev) return NZ_ERR_ARG;
   SCS_HIP(h, hipSetDevice(h->device));
-  hipLaunchKernelGGL(scs_image_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->states,
+  hipLaunchKernelGGL(scs_image_kernel, dim3(blocks(h->n_games)), dim3(128), 0, (hipStream_t)stream, h->rules, h->rules_stride, h->states,
                      image_dev, h->n_games);
   SCS_HIP(h, hipGetLastError());
   return NZ_OK;

@@ -47,6 +47,7 @@ struct ScsRules {                     // immutable game description (one per eng
 };
 
 bool scs_fill_rules(const nz_scs_desc* d, ScsRules* out, std::string* err);   // scs.hip (host)
+void scs_apply_map(ScsRules* r, const float* terrain, const int32_t* vp);      // scs.hip (host): a game's own map
 
 struct ScsState {
   int16_t stage, turn, length;

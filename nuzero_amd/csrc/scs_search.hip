@@ -58,7 +58,8 @@ struct SearchParams {
   double frac, one_minus_frac, value_factor, eps_softmax, eps_random;
   const double* bias_tab;
   const double* sqrt_tab;
-  const ScsRules* rules;
+  const ScsRules* rules;   // the game description; with per-game maps (nz_scs_search_set_games) one row per game of the round
+  const int32_t* rules_row;  // [G] the row of `rules` each slot's game reads, or nullptr: all read row 0
   ScsState* real;          // [G]
   ScsState* scratch;       // [G]
   SNode* nodes;            // [G][2][half_cap]: two halves per game, the live tree is in half `half[g]`
@@ -209,6 +210,10 @@ __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 he
   return res;
 }
 
+__device__ __forceinline__ const ScsRules& rules_of(const SearchParams& p, int g) {
+  return p.rules[p.rules_row ? p.rules_row[g] : 0];
+}
+
 // the half of game g's arena that holds its live tree
 __device__ __forceinline__ SNode* arena(const SearchParams& p, int g) {
   return p.nodes + (size_t)g * p.cap + (size_t)p.half[g] * p.half_cap;
@@ -222,7 +227,7 @@ __global__ void search_reset_kernel(SearchParams p) {
       if (i < 8 || i > 10) p.counters[i] = 0;      // [8..10] belong to the inference cache (nz_scs_search_cache)
   }
   if (g >= p.n_games) return;
-  Scs(*p.rules, p.real[g]).reset();
+  Scs(rules_of(p, g), p.real[g]).reset();
   p.half[g] = 0;
   SNode& n = p.nodes[(size_t)g * p.cap];
   n.prior = 0.0; n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = 0;
@@ -282,7 +287,7 @@ __global__ void archive_kernel(SearchParams p, RoundStore st, const int32_t* __r
 __global__ void restart_kernel(SearchParams p, const int32_t* __restrict__ restart) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= p.n_games || !restart[g]) return;
-  Scs(*p.rules, p.real[g]).reset();
+  Scs(rules_of(p, g), p.real[g]).reset();
   p.half[g] = 0;
   SNode& n = p.nodes[(size_t)g * p.cap];
   n.prior = 0.0; n.value_sum = 0.0; n.visit = 0; n.child_base = 0; n.n_children = 0; n.action = 0;
@@ -522,7 +527,8 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
   {   // rules -> LDS: 16 bytes per lane and load, all loads in flight before the first store
     static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
     constexpr int N16 = (int)(sizeof(ScsRules) / 16), PER_LANE = (N16 + 63) / 64;
-    const uint4* src = reinterpret_cast<const uint4*>(p.rules);
+    const ScsRules* const my_rules = &rules_of(p, g);
+    const uint4* src = reinterpret_cast<const uint4*>(my_rules);
     uint4* dst = reinterpret_cast<uint4*>(&R);
     uint4 tmp[PER_LANE];
 #pragma unroll
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 #pragma unroll
     for (int j = 0; j < PER_LANE; ++j)
       if (j * 64 + lane < N16) dst[j * 64 + lane] = tmp[j];
-    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(p.rules);
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(my_rules);
     uint32_t* d4 = reinterpret_cast<uint32_t*>(&R);
     for (int i = N16 * 4 + lane; i < (int)(sizeof(ScsRules) / 4); i += 64) d4[i] = s4[i];
   }
@@ -696,7 +702,8 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
 struct PersistArgs {
   const Fused16Program* prog;
   int32_t net_floats, stage_off, stage_floats, inp, in_channels;
-  int32_t wave_bytes;             // a wavefront's LDS block: real game, scratch game, legal mask, legal list, network
+  int32_t wave_bytes;             // a game's LDS block: real game, scratch game, legal mask, legal list, flags, network
+  int32_t rules_per_game;         // 1: every game slot keeps its own description in LDS (per-game maps), 0: one for the workgroup
   // leaf evaluations of chosen games, for the oracle replay of tests/scs_replay.py (null: none)
   const int32_t* rec_slot;        // [G] slot or -1
   int32_t rec_cap;
@@ -1289,23 +1296,28 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
 template <bool HEX>
 __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p, PersistArgs q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  ScsRules& R = *reinterpret_cast<ScsRules*>(smem);
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // wavefronts 0..3 lead games 0..3; wavefront 4 + i helps game (i + 3) & 3, so that every SIMD hosts one leader and
   // one helper of ANOTHER game (a helper sleeps through its game's tree phases)
   const bool leader = wave < PERSIST_GAMES;
   const int slot = leader ? wave : ((wave - PERSIST_GAMES + 3) & (PERSIST_GAMES - 1));
+  const int n_rules = q.rules_per_game ? PERSIST_GAMES : 1;       // descriptions in LDS: one, or one per game slot (its own map)
+  const ScsRules& R = *reinterpret_cast<const ScsRules*>(smem + (size_t)(q.rules_per_game ? slot : 0) * PERSIST_RULES_BYTES);
   {   // rules -> LDS, once per workgroup, and the games' flag words; the only workgroup barrier of the kernel
     static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(p.rules);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
-    for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_THREADS) dst[i] = src[i];
+    for (int r = 0; r < n_rules; ++r) {
+      const int gr = blockIdx.x * PERSIST_GAMES + r;
+      if (gr >= p.n_games) break;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&rules_of(p, gr));
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)r * PERSIST_RULES_BYTES);
+      for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_THREADS) dst[i] = src[i];
+    }
     if (threadIdx.x < PERSIST_GAMES * 4)
-      reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+      reinterpret_cast<int*>(smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
   }
   __syncthreads();
-  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
+  unsigned char* const wb = smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
   int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
   int* const go = flags + 2;
   const int g = blockIdx.x * PERSIST_GAMES + slot;
@@ -1382,7 +1394,7 @@ __global__ void end_move_kernel(SearchParams p, const double* __restrict__ unifo
   if (g >= p.n_games) return;
   ScsState& real = p.real[g];
   if (real.terminal) return;
-  const ScsRules& R = *p.rules;
+  const ScsRules& R = rules_of(p, g);
   SNode* nodes = arena(p, g);
   const SNode root = nodes[p.root[g]];
   const int k = root.n_children, move = real.length;
@@ -1530,10 +1542,20 @@ struct nz_scs_search {
   // persistent route (persist_kernel): -1 follow the default (on where the network has a per-wavefront form), 0 off, 1 on
   int persist_mode = -1;
   int persist_used = 0;                       // the last play ran on it
+  bool persist_profile = false;               // HIP events around every persist_kernel launch (nz_scs_search_persist_profile)
+  hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
+  double persist_ms = 0.0;
+  int64_t persist_launches = 0, persist_mfmas = 0, persist_flops = 0;
   std::string persist_why;                    // why not
   PersistArgs pq{};
   int32_t* rec_slot_dev = nullptr;
   int32_t rec_slots = 0;
+  // per-game maps and streams of the next plays (nz_scs_search_set_games)
+  ScsRules* base_rules_dev = nullptr;         // the description of nz_scs_search_create (one row)
+  ScsRules* game_rules_dev = nullptr;         // [n_game_rows]
+  int32_t* rules_row_dev = nullptr;           // [n_games]
+  int64_t n_game_rows = 0;
+  std::vector<nz_rng*> game_streams;          // [n_game_rows] or empty: streams from the seeds
 };
 
 namespace {
@@ -1699,6 +1721,8 @@ nz_status nz_scs_search_create(nz_scs_search** out, const nz_scs_desc* d, const 
   p.clear_counters = nullptr;
   h->counters_base = p.leaf_count;
   p.rules = rules;
+  p.rules_row = nullptr;
+  h->base_rules_dev = rules;
   p.bias_tab = bias;
   p.sqrt_tab = sq;
   hipLaunchKernelGGL(search_reset_kernel, dim3((n_games + 127) / 128), dim3(128), 0, nullptr, p);
@@ -1714,6 +1738,7 @@ void nz_scs_search_destroy(nz_scs_search* h) {
   for (void* q : h->allocs) (void)hipFree(q);
   if (h->active_pinned) (void)hipHostFree(h->active_pinned);
   if (h->ev_poll) (void)hipEventDestroy(h->ev_poll);
+  if (h->ev_p0) { (void)hipEventDestroy(h->ev_p0); (void)hipEventDestroy(h->ev_p1); }
   {
     const RoundStore& r = h->round;
     void* store[] = {r.action, r.tree_size, r.children, r.child_action, r.child_visit, r.status, r.bias, r.root_value_sum,
@@ -1726,6 +1751,9 @@ void nz_scs_search_destroy(nz_scs_search* h) {
     (void)hipFree(h->rec_slot_dev); (void)hipFree(h->pq.rec_count); (void)hipFree(h->pq.rec_digest);
     (void)hipFree(h->pq.rec_probs); (void)hipFree(h->pq.rec_value);
   }
+  if (h->game_rules_dev) (void)hipFree(h->game_rules_dev);
+  if (h->rules_row_dev) (void)hipFree(h->rules_row_dev);
+  for (nz_rng* r : h->game_streams) nz_rng_destroy(r);
   delete h;
 }
 
@@ -1866,7 +1894,7 @@ nz_status round_store(nz_scs_search* h, int64_t n) {
 // wherever and whenever it runs, so the round's games do not depend on the number of slots.
 nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_host, int64_t n_round, int32_t max_moves,
                     void* stream) {
-  if (!h || !net || (h->cfg.training && !seeds_host)) return sfail(h, NZ_ERR_ARG, "null argument");
+  if (!h || !net || (h->cfg.training && !seeds_host && h->game_streams.empty())) return sfail(h, NZ_ERR_ARG, "null argument");
   const bool refill = n_round > h->n_games;
   if (n_round < h->n_games) return sfail(h, NZ_ERR_ARG, "a round has at least one game per slot (%d)", h->n_games);
   if (refill && max_moves > 0) return sfail(h, NZ_ERR_ARG, "max_moves applies to one game per slot only");
@@ -1912,8 +1940,10 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
       PersistArgs& q = h->pq;
       q.prog = wn.prog; q.net_floats = wn.lds_floats; q.stage_off = wn.stage_off; q.stage_floats = wn.stage_floats;
       q.inp = wn.inp; q.in_channels = wn.in_channels;
+      h->persist_mfmas = wn.mfmas; h->persist_flops = wn.flops;
       q.wave_bytes = PERSIST_GAME_BYTES + (wn.lds_floats * 4 + 15) / 16 * 16;
-      persist_lds = (size_t)PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
+      q.rules_per_game = h->n_game_rows > 0 ? 1 : 0;
+      persist_lds = (size_t)(q.rules_per_game ? PERSIST_GAMES : 1) * PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
       if (persist_lds > 160 * 1024) h->persist_why = "four games' blocks do not fit in LDS";
       else {
         const hipError_t e = wn.hex
@@ -1933,8 +1963,22 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     std::vector<nz_rng*>& v;
     ~RngGuard() { for (nz_rng* r : v) nz_rng_destroy(r); }
   } guard{rngs};
+  const bool own_games = h->n_game_rows > 0;       // per-game maps (and streams) from nz_scs_search_set_games
+  if (own_games && n_round > h->n_game_rows)
+    return sfail(h, NZ_ERR_ARG, "%lld games in the round, %lld set with nz_scs_search_set_games", (long long)n_round, (long long)h->n_game_rows);
+  // the stream of game i of the round: where its map's draws left it (set_games), else RandomState(seeds_host[i])
+  auto new_stream = [&](int64_t i) -> nz_rng* {
+    if (!h->game_streams.empty()) return nz_rng_clone(h->game_streams[(size_t)i]);
+    return nz_rng_create(seeds_host[i]);
+  };
   if (h->cfg.training)
-    for (int g = 0; g < G; ++g) rngs.push_back(nz_rng_create(seeds_host[g]));
+    for (int g = 0; g < G; ++g) rngs.push_back(new_stream(g));
+  std::vector<int32_t> rules_rows(G);
+  if (own_games) {
+    for (int g = 0; g < G; ++g) rules_rows[g] = g;
+    S_HIP(h, hipMemcpyAsync(h->rules_row_dev, rules_rows.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
+    S_HIP(h, hipStreamSynchronize((hipStream_t)stream));
+  }
   std::vector<int32_t> status((size_t)G * 7), nchild(G);
   std::vector<double> noise((size_t)G * MAXC), uni((size_t)G * 3);
   nz_status st = nz_scs_search_reset(h, stream);
@@ -1972,8 +2016,9 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
           slot_game[g] = (int32_t)next_game;
           if (h->cfg.training) {
             nz_rng_destroy(rngs[g]);
-            rngs[g] = nz_rng_create(seeds_host[next_game]);
+            rngs[g] = new_stream(next_game);
           }
+          rules_rows[g] = (int32_t)next_game;          // (its own map, where the games have them)
           ++next_game;
           restart[g] = 1;
           restarted = true;
@@ -1986,6 +2031,8 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
         hipLaunchKernelGGL(archive_kernel, dim3(G), dim3(64), 0, s, h->p, h->round, h->to_record);
       }
       if (restarted) {
+        if (own_games)
+          S_HIP(h, hipMemcpyAsync(h->rules_row_dev, rules_rows.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, s));
         S_HIP(h, hipMemcpyAsync(h->restart, restart.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(restart_kernel, grid1, block1, 0, s, h->p, h->restart);
         hipLaunchKernelGGL(search_status_kernel, grid1, block1, 0, s, h->p, h->status);
@@ -2038,6 +2085,10 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     h->p.terminal_budget = 1;                  // measured best (bench_scs.py: 1 -> 308 games/s, 16 -> 259, unbounded -> 226)
     if (const char* e = getenv("NZ_SCS_TERMINAL_BUDGET")) h->p.terminal_budget = std::max(1, atoi(e));   // tuning experiments
     if (persist) {                               // the whole move's search of every game: one launch
+      if (h->persist_profile) {
+        if (!h->ev_p0) { S_HIP(h, hipEventCreate(&h->ev_p0)); S_HIP(h, hipEventCreate(&h->ev_p1)); }
+        S_HIP(h, hipEventRecord(h->ev_p0, s));
+      }
       if (h->persist_used == 2)
         hipLaunchKernelGGL(persist_kernel<true>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       else
@@ -2053,8 +2104,15 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
         fprintf(stderr, "move %lld: %d live games, %.3f ms\n", (long long)move, live,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
       }
-      st = nz_scs_search_end_move(h, h->uniforms, stream);
+      if (h->persist_profile) S_HIP(h, hipEventRecord(h->ev_p1, s));
+      st = nz_scs_search_end_move(h, h->uniforms, stream);     // (synchronises)
       if (st != NZ_OK) return st;
+      if (h->persist_profile) {
+        float ms = 0.f;
+        S_HIP(h, hipEventElapsedTime(&ms, h->ev_p0, h->ev_p1));
+        h->persist_ms += ms;
+        ++h->persist_launches;
+      }
       continue;
     }
     const int sims = h->cfg.mcts_simulations;
@@ -2217,6 +2275,70 @@ nz_status nz_scs_search_persistent(nz_scs_search* h, int32_t enable, int32_t* us
   if (!h) return NZ_ERR_ARG;
   if (enable >= -1 && enable <= 1) h->persist_mode = enable;
   if (used) *used = h->persist_used ? 1 : 0;
+  return NZ_OK;
+}
+
+// Every game of the next plays on its OWN map, as the reference builds a new game object -- and with a "Randomized"
+// config a new map -- per game (Training/Gamer.py:52, SCS_Game.py:1678-1738).  Host arrays for n games (n >= the games of
+// a round): terrain float32 [n][tiles][3] (attack modifier, defense modifier, cost), vp int32 [n][n_vp0 + n_vp1][2] (row,
+// column); and, optionally, the random stream each game goes on with after its map's draws (numpy RandomState state:
+// mt_keys uint32 [n][624], mt_pos int32 [n]; NULL: the plays' seeds make the streams).  n = 0: back to the description's
+// one map.  Game i of a round reads row i whichever slot plays it.
+nz_status nz_scs_search_set_games(nz_scs_search* h, int64_t n, const float* terrain_host, const int32_t* vp_host,
+                                  const uint32_t* mt_keys_host, const int32_t* mt_pos_host) {
+  if (!h || n < 0 || (n > 0 && (!terrain_host || !vp_host)) || ((mt_keys_host == nullptr) != (mt_pos_host == nullptr)))
+    return NZ_ERR_ARG;
+  S_HIP(h, hipSetDevice(h->device));
+  S_HIP(h, hipDeviceSynchronize());
+  for (nz_rng* r : h->game_streams) nz_rng_destroy(r);
+  h->game_streams.clear();
+  if (h->game_rules_dev) { (void)hipFree(h->game_rules_dev); h->game_rules_dev = nullptr; }
+  h->n_game_rows = 0;
+  h->p.rules = h->base_rules_dev;
+  h->p.rules_row = nullptr;
+  if (n == 0) return nz_scs_search_reset(h, nullptr);
+  if (n < h->n_games) return sfail(h, NZ_ERR_ARG, "%lld games set, the engine plays %d at a time", (long long)n, h->n_games);
+  const ScsRules& b = h->host_rules;
+  const int T = b.tiles, nv = b.n_vp[0] + b.n_vp[1];
+  std::vector<ScsRules> rows((size_t)n, b);
+  for (int64_t i = 0; i < n; ++i) {
+    nz::scs_apply_map(&rows[(size_t)i], terrain_host + (size_t)i * T * 3, vp_host + (size_t)i * nv * 2);
+    for (int t = 0; t < T; ++t)
+      if (rows[(size_t)i].cost[t] < 1) return sfail(h, NZ_ERR_ARG, "game %lld: a terrain with movement cost < 1", (long long)i);
+  }
+  if (hipMalloc((void**)&h->game_rules_dev, rows.size() * sizeof(ScsRules)) != hipSuccess)
+    return sfail(h, NZ_ERR_HIP, "device allocation failed (%lld game descriptions)", (long long)n);
+  S_HIP(h, hipMemcpy(h->game_rules_dev, rows.data(), rows.size() * sizeof(ScsRules), hipMemcpyHostToDevice));
+  if (!h->rules_row_dev && hipMalloc((void**)&h->rules_row_dev, (size_t)h->n_games * sizeof(int32_t)) != hipSuccess)
+    return sfail(h, NZ_ERR_HIP, "device allocation failed");
+  std::vector<int32_t> ident(h->n_games);
+  for (int g = 0; g < h->n_games; ++g) ident[g] = g;
+  S_HIP(h, hipMemcpy(h->rules_row_dev, ident.data(), ident.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (mt_keys_host)
+    for (int64_t i = 0; i < n; ++i) {
+      nz_rng* r = nz_rng_create_state(mt_keys_host + (size_t)i * 624, mt_pos_host[i], 0, 0.0);
+      if (!r) return sfail(h, NZ_ERR_ARG, "game %lld: bad stream position %d", (long long)i, mt_pos_host[i]);
+      h->game_streams.push_back(r);
+    }
+  h->n_game_rows = n;
+  h->p.rules = h->game_rules_dev;
+  h->p.rules_row = h->rules_row_dev;
+  return nz_scs_search_reset(h, nullptr);      // the slots' games start on their own maps (row g for slot g)
+}
+
+// HIP-event timing of the persistent kernel on the stream it runs on.  enable >= 0: switch (1 also zeroes the sums).
+// out4 (may be NULL): milliseconds summed over launches, launches, v_mfma_f32_16x16x32_bf16 per position, algorithmic
+// float32 FLOPs per position.
+nz_status nz_scs_search_persist_profile(nz_scs_search* h, int32_t enable, double* out4_host) {
+  if (!h) return NZ_ERR_ARG;
+  if (enable >= 0) {
+    h->persist_profile = enable != 0;
+    if (enable) { h->persist_ms = 0.0; h->persist_launches = 0; }
+  }
+  if (out4_host) {
+    out4_host[0] = h->persist_ms; out4_host[1] = (double)h->persist_launches;
+    out4_host[2] = (double)h->persist_mfmas; out4_host[3] = (double)h->persist_flops;
+  }
   return NZ_OK;
 }
 

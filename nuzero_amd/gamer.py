@@ -171,8 +171,11 @@ class Gamer:
             from .scs import ScsGameConfig, ScsSelfPlay
             if not game_args:
                 raise ValueError("SCS needs game_args = [path of the game config]")
-            # ([config path, map_seed]: a "Randomized" config with the map the reference draws after np.random.seed(map_seed))
-            self.scs_config = ScsGameConfig(game_args[0], *game_args[1:2])
+            # A "Randomized" config gives every game its own map, as the reference's Gamer builds a game object -- and with
+            # it a map -- per game (Gamer.py:52; SCS_Game.py:1678-1738): game i of a round is
+            # `np.random.seed(base_seed + i); SCS_Game(config); play` -- one stream, the map's draws first.
+            # [config path, map_seed] instead plays every game on the ONE map drawn after np.random.seed(map_seed).
+            self.scs_config = ScsGameConfig(game_args[0], *game_args[1:2], per_game=len(game_args) < 2)
             # `concurrent_games` trees play the round's `num_games` games: a tree whose game has ended starts the round's
             # next one (the reference's ActorPool of num_actors Gamers over num_games_per_step games, AlphaZero.py:525-577;
             # games are independent and seeded by their index, so which tree plays a game does not change it)

@@ -233,6 +233,8 @@ class DeviceReplayBuffer:
         kept = self.index.save_games(lengths[:n_keep], game_index)
         dst[:n_keep, :kept.shape[1]] = kept
         batch = ScsBatch(cfg, G, device=self.device.index or 0)
+        if cfg.per_game:                                      # every game is replayed on its own map
+            batch.set_maps(selfplay.game_maps[0][:G], selfplay.game_maps[1][:G])
         outcomes = r["outcomes"].to(torch.int32).contiguous()
         moves = torch.arange(int(lengths.max()), device=self.device)
         actions = torch.where(moves[None, :] < r["lengths"][:, None].to(self.device), r["actions"][:, :len(moves)],

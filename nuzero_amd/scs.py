@@ -21,8 +21,9 @@ def randomized_map(d, rows, cols, p1_last, p2_first, seed):
     numpy's global stream was seeded with `seed` just before: the sections in file order, a tile's terrain by
     np.random.choice(terrain_types, p=distribution) row by row, a victory point by np.random.choice(range(rows)) and
     np.random.choice(range(columns of the player's side)), redrawn while it repeats an earlier one.  Returns
-    (terrain id map or None, (p1 points, p2 points) or None)."""
-    rs = np.random.RandomState(seed)
+    (terrain id map or None, (p1 points, p2 points) or None).  `seed` may be a RandomState: it is drawn from and left
+    where the game's own draws go on."""
+    rs = seed if isinstance(seed, np.random.RandomState) else np.random.RandomState(seed)
     ids = [int(p["id"]) for p in d["Terrain"].values()]          # terrain_types: the Terrain section's order
     tmap = vps = None
     for section, values in d.items():
@@ -42,15 +43,18 @@ def randomized_map(d, rows, cols, p1_last, p2_first, seed):
 
 
 class ScsGameConfig:
-    def __init__(self, path_or_dict, map_seed=None):
-        """`map_seed`: for configs with "Randomized" maps or victory points -- the map SCS_Game(config) builds when
-        np.random.seed(map_seed) was called just before (the reference draws from numpy's global stream at load time, a
-        new map per game object; here one map per config object, i.e. per engine and round)."""
+    def __init__(self, path_or_dict, map_seed=None, per_game=False):
+        """`map_seed`: for configs with "Randomized" maps or victory points -- the ONE map SCS_Game(config) builds when
+        np.random.seed(map_seed) was called just before.  `per_game=True` (what the reference does: it draws from numpy's
+        global stream whenever a game object is built, and Gamer builds one per game, Training/Gamer.py:52): every game
+        gets its own map, drawn by `draw_game(rs)` from the game's own stream; this object then only holds a TEMPLATE
+        map (the cheapest terrain everywhere: it bounds game lengths for the engine's limits)."""
         if isinstance(path_or_dict, dict):
             d = path_or_dict
         else:
             with open(path_or_dict) as f:
                 d = yaml.safe_load(f)
+        self.per_game = False
         self.rows, self.cols = int(d["Board_dimensions"]["rows"]), int(d["Board_dimensions"]["columns"])
         self.turns, self.stacking = int(d["Turns"]), int(d["Stacking_limit"])
         mid = self.cols // 2                    # the board's two sides (define_board_sides, :1140-1158)
@@ -59,10 +63,20 @@ class ScsGameConfig:
         else:
             side_p1_last, side_p2_first = max(0, mid - 2), min(self.cols - 1, mid + 1)
         if d["Map"]["creation_method"] != "Detailed" or d["Victory_points"]["creation_method"] != "Detailed":
-            if map_seed is None:
+            if map_seed is None and not per_game:
                 raise NotImplementedError("'Randomized' maps / victory points draw from numpy's global stream at load "
-                                          "time (SCS_Game.py:1683-1738): pass map_seed")
-            rmap, rvps = randomized_map(d, self.rows, self.cols, side_p1_last, side_p2_first, map_seed)
+                                          "time (SCS_Game.py:1683-1738): pass map_seed (one map) or per_game=True")
+            if per_game and map_seed is None:
+                self.per_game = True
+                self._random = (d, side_p1_last, side_p2_first)
+                cheapest = min(d["Terrain"].values(), key=lambda t: t["cost"])["id"]
+                rmap = [[cheapest] * self.cols for _ in range(self.rows)] if d["Map"]["creation_method"] != "Detailed" else None
+                rvps = None
+                if d["Victory_points"]["creation_method"] != "Detailed":
+                    n1, n2 = (int(d["Victory_points"]["number_vp"][k]) for k in ("p1", "p2"))
+                    rvps = ([(i % self.rows, 0) for i in range(n1)], [(i % self.rows, self.cols - 1) for i in range(n2)])
+            else:
+                rmap, rvps = randomized_map(d, self.rows, self.cols, side_p1_last, side_p2_first, map_seed)
             d = dict(d)
             if rmap is not None:
                 d["Map"] = {"creation_method": "Detailed", "map_configuration": rmap}
@@ -71,6 +85,7 @@ class ScsGameConfig:
                                        "vp_locations": {"p1": [list(p) for p in rvps[0]], "p2": [list(p) for p in rvps[1]]}}
         units = {int(p["id"]): p for p in d["Units"].values()}
         terrain = {int(p["id"]): p for p in d["Terrain"].values()}
+        self._terrain_by_id = terrain
         tmap = np.asarray(d["Map"]["map_configuration"])
         if tmap.shape != (self.rows, self.cols):
             raise ValueError("Wrong shape for map configuration")
@@ -114,6 +129,35 @@ class ScsGameConfig:
         self.num_actions = self.planes * self.rows * self.cols
         self.channels = 3 + 2 + 36 + 2 * 9 * s + 1 + s + 4 + 1 + 1
 
+    def draw_game(self, rs):
+        """One game's own map, drawn from the RandomState `rs` as SCS_Game(config) draws it from numpy's global stream
+        (SCS_Game.py:1678-1738); `rs` is left where the game's play goes on.  Returns (terrain float32 [tiles, 3], victory
+        points int32 [n_vp0 + n_vp1, 2]); parts the config gives in "Detailed" form are the config's."""
+        assert self.per_game
+        d, p1_last, p2_first = self._random
+        rmap, rvps = randomized_map(d, self.rows, self.cols, p1_last, p2_first, rs)
+        t = self.terrain if rmap is None else np.array(
+            [[self._terrain_by_id[int(i)]["attack_modifier"], self._terrain_by_id[int(i)]["defense_modifier"],
+              self._terrain_by_id[int(i)]["cost"]] for row in rmap for i in row], np.float32)
+        v = self.vp if rvps is None else np.array(list(rvps[0]) + list(rvps[1]), np.int32).reshape(-1, 2)
+        return t, v
+
+    def draw_games(self, seeds):
+        """`draw_game` for RandomState(seed) of every seed: (terrain [n, tiles, 3], vp [n, k, 2], the streams' states after
+        the draws: MT19937 keys uint32 [n, 624] and positions int32 [n], the RandomStates themselves)."""
+        n = len(seeds)
+        terrain = np.empty((n, self.rows * self.cols, 3), np.float32)
+        vp = np.empty((n, len(self.vp), 2), np.int32)
+        keys, pos, streams = np.empty((n, 624), np.uint32), np.empty((n,), np.int32), []
+        for i, s in enumerate(seeds):
+            rs = np.random.RandomState(int(s))
+            terrain[i], vp[i] = self.draw_game(rs)
+            st = rs.get_state()
+            assert st[3] == 0                      # (no cached Gaussian: choice() never draws one)
+            keys[i], pos[i] = st[1], st[2]
+            streams.append(rs)
+        return terrain, vp, keys, pos, streams
+
 
 class ScsBatch:
     def __init__(self, config, n_games, device=0):
@@ -153,6 +197,16 @@ class ScsBatch:
 
     def reset(self):
         self._check(lib.nz_scs_reset(self._h, self._stream()))
+
+    def set_maps(self, terrain, vp):
+        """Every game of the batch on its own map (float32 [G, tiles, 3], int32 [G, k, 2]; None: the config's); resets."""
+        if terrain is None:
+            self._check(lib.nz_scs_set_maps(self._h, None, None, self._stream()))
+            return
+        t = np.ascontiguousarray(terrain, np.float32)
+        v = np.ascontiguousarray(vp, np.int32)
+        assert t.shape == (self.n_games, self.cfg.rows * self.cfg.cols, 3) and v.shape == (self.n_games, len(self.cfg.vp), 2)
+        self._check(lib.nz_scs_set_maps(self._h, c_void_p(t.ctypes.data), c_void_p(v.ctypes.data), self._stream()))
 
     def step(self, actions):
         a = torch.as_tensor(actions, dtype=torch.int32).to(self.device).contiguous()
@@ -238,14 +292,27 @@ class ScsSelfPlay:
         self._check(lib.nz_scs_search_status(self._h, c_void_p(s.data_ptr()), self._stream()))
         return s.cpu().numpy()
 
+    def set_games(self, seeds):
+        """Per-game maps (configs made with per_game=True): game i = `np.random.seed(seeds[i]); SCS_Game(config)`, its map
+        drawn first and its play going on with the same stream (nz_scs_search_set_games).  Keeps the maps in
+        `self.game_maps` = (terrain [n, tiles, 3], vp [n, k, 2]) for whoever replays the games.  Returns the streams."""
+        terrain, vp, keys, pos, streams = self.cfg.draw_games(seeds)
+        self._check(lib.nz_scs_search_set_games(self._h, len(seeds), c_void_p(terrain.ctypes.data), c_void_p(vp.ctypes.data),
+                                                c_void_p(keys.ctypes.data), c_void_p(pos.ctypes.data)))
+        self.game_maps = (terrain, vp)
+        return streams
+
     def play(self, evaluator, seeds, max_moves=None):
         """Reset and play every game to the end (or for `max_moves` decisions); game g draws from
         RandomState(seeds[g]) in the reference's order (gamma x n_root_children, two uniforms, at most one
         more for choice).  `evaluator` may take a second argument: the game index of every leaf."""
         ex = self.search_config["Exploration"]
         G, A = self.n_games, self.cfg.num_actions
-        rngs = [np.random.RandomState(int(s)) for s in seeds]
-        self._check(lib.nz_scs_search_reset(self._h, self._stream()))
+        if self.cfg.per_game:
+            rngs = self.set_games(list(seeds))         # (resets; every stream stands behind its map's draws)
+        else:
+            rngs = [np.random.RandomState(int(s)) for s in seeds]
+            self._check(lib.nz_scs_search_reset(self._h, self._stream()))
         nchild_dev = torch.empty((G,), dtype=torch.int32, device=self.device)
         import inspect
         wants_games = len(inspect.signature(evaluator).parameters) >= 2
@@ -332,6 +399,8 @@ class ScsSelfPlay:
         host only draws the per-move random numbers.  Same games as play(net.evaluator(), seeds)."""
         seeds = np.ascontiguousarray(np.asarray(list(seeds), dtype=np.uint32))
         assert seeds.shape == (self.n_games,)
+        if self.cfg.per_game:
+            self.set_games(seeds.tolist())
         self._check(lib.nz_scs_search_play_moves(self._h, net._h, c_void_p(seeds.ctypes.data), int(max_moves or 0),
                                                  self._stream()))
         out = self.export()
@@ -348,6 +417,12 @@ class ScsSelfPlay:
         used = ctypes.c_int32(0)
         self._check(lib.nz_scs_search_persistent(self._h, int(enable), byref(used)))
         return bool(used.value)
+
+    def persist_profile(self, enable=-1):
+        """HIP-event time of the persistent kernel (nz_scs_search_persist_profile): enable 1 / 0 switches, -1 reads."""
+        out = (ctypes.c_double * 4)()
+        self._check(lib.nz_scs_search_persist_profile(self._h, int(enable), out))
+        return {"ms": out[0], "launches": int(out[1]), "mfma_per_position": int(out[2]), "flops_per_position": int(out[3])}
 
     def persist_ticks(self):
         """Diagnostic build (-DNZ_PERSIST_STAMPS) only: shader ticks per phase of the persistent kernel."""
@@ -392,6 +467,8 @@ class ScsSelfPlay:
         seeds = np.ascontiguousarray(np.asarray(list(seeds), dtype=np.uint32))
         n = int(seeds.shape[0])
         waves = ctypes.c_int64(0)
+        if self.cfg.per_game:
+            self.set_games(seeds.tolist())
         if n == self.n_games:
             self._check(lib.nz_scs_search_play_moves(self._h, net._h, c_void_p(seeds.ctypes.data), 0, self._stream()))
             t = self.export_device()
@@ -521,6 +598,8 @@ def scs_game_records(selfplay, result):
     lengths = result["lengths"]
     cfg, G = selfplay.cfg, int(lengths.shape[0])        # rows of the round (>= selfplay.n_games after play_round)
     batch = ScsBatch(cfg, G, device=selfplay.device.index or 0)
+    if cfg.per_game:
+        batch.set_maps(selfplay.game_maps[0][:G], selfplay.game_maps[1][:G])
     L = int(lengths.max())
     states = np.zeros((G, L, cfg.channels, cfg.rows, cfg.cols), np.float32)
     for m in range(L):

@@ -30,7 +30,9 @@ class Unit:
 
 class ScsConfig:
     """The game description of SCS_Game.load_game_from_config (:1570-1779).  "Randomized" maps and victory points
-    (:1678-1738) need `map_seed`: what the reference draws from numpy's global stream after np.random.seed(map_seed)."""
+    (:1678-1738) need `map_seed`: what the reference draws from numpy's global stream after np.random.seed(map_seed).
+    `map_seed` may also be a RandomState: the map is then drawn from it and the stream is left where the game's own
+    draws continue (a game object built and played from one stream: a new map per game, Training/Gamer.py:52)."""
 
     def __init__(self, path, map_seed=None):
         with open(path) as f:
@@ -74,7 +76,7 @@ class ScsConfig:
         vp = d["Victory_points"].get("vp_locations")
         if d["Map"]["creation_method"] != "Detailed" or d["Victory_points"]["creation_method"] != "Detailed":
             assert map_seed is not None, "Randomized methods draw from numpy's global stream: pass map_seed"
-            rs = np.random.RandomState(map_seed)
+            rs = map_seed if isinstance(map_seed, np.random.RandomState) else np.random.RandomState(map_seed)
             ids = [t["id"] for t in d["Terrain"].values()]            # self.terrain_types, in the section's order (:1665-1676)
             for section, values in d.items():                        # the sections in file order (:1582)
                 if section == "Map" and values["creation_method"] == "Randomized":          # :1679-1690

@@ -1,0 +1,139 @@
+"""Every SCS game on its OWN "Randomized" map -- what the reference's SCS presets train on (Run.py:115;
+SCS_Game.py:1678-1738 draws terrain and victory points when a game object is built, Training/Gamer.py:52 builds one per
+game) -- on the HIP path, against fixtures the genuine SCS_Game / Explorer made (tests/golden/make_golden_scs_pergame.py):
+the device rules and the device search on per-game maps equal them bit for bit; 1024 different maps play in one engine.
+Seeding rule: game with seed s = np.random.seed(s); SCS_Game(config); play -- one stream, the map's draws first.
+Needs a GPU."""
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(HERE, "golden")
+PATH = os.path.join(GOLDEN, "scs_configs", "randomized_5x5.yml")
+
+
+def checksum_weights(n):
+    i = np.arange(n, dtype=np.int64)
+    return ((i * 2654435761) % 1000003).astype(np.float64) / 1000003.0
+
+
+def test_device_rules_on_per_game_maps_equal_the_reference():
+    """24 games side by side in ONE batch, each on its own map (nz_scs_set_maps), replaying what the genuine SCS_Game
+    played: turn machine registers, legal sets, state images of every step."""
+    from nuzero_amd.scs import ScsBatch, ScsGameConfig
+    kat = dict(np.load(os.path.join(GOLDEN, "scs_pergame_kat.npz")))
+    cfg = ScsGameConfig(PATH, per_game=True)
+    G = len(kat["lengths"])
+    terrain, vp, _, _, _ = cfg.draw_games(kat["map_seed"].tolist())
+    assert np.array_equal(terrain.reshape(G, cfg.rows, cfg.cols, 3).astype(np.float64), kat["terrain"])
+    assert len({t.tobytes() for t in terrain}) == G                    # 24 different maps
+    batch = ScsBatch(cfg, G)
+    batch.set_maps(terrain, vp)
+    planes, rows, cols, channels, _, _ = kat["shape"]
+    w = checksum_weights(channels * rows * cols)
+    first = np.concatenate([[0], np.cumsum(kat["lengths"])[:-1]])         # every game's first row in the step arrays
+    legal_at = np.concatenate([[0], np.cumsum(kat["n_legal"])])
+    images = {int(s): img for s, img in zip(kat["image_step"], kat["images"])}
+    n_images = 0
+    for m in range(int(kat["lengths"].max()) + 1):
+        st = batch.status().cpu().numpy()
+        mask = batch.legal_mask().cpu().numpy().reshape(G, -1)
+        img = batch.state_image().cpu().numpy()
+        actions = np.full(G, -1, np.int32)
+        for g in range(G):
+            if m >= kat["lengths"][g]:
+                assert st[g, 4] == 1 and st[g, 5] == kat["values"][g] and st[g, 6] == kat["lengths"][g]
+                assert np.array_equal(img[g], images[-(g + 1)])
+                continue
+            i = int(first[g]) + m
+            assert tuple(st[g, :4]) == (kat["player"][i], kat["sub_phase"][i], kat["stage"][i], kat["turn"][i]), (g, m)
+            assert np.nonzero(mask[g])[0].tolist() == kat["legal"][legal_at[i]:legal_at[i + 1]].tolist(), (g, m)
+            assert float(np.sum(img[g].reshape(-1).astype(np.float64) * w)) == kat["checksum"][i], (g, m)
+            if i in images:
+                assert np.array_equal(img[g], images[i]), (g, m)
+                n_images += 1
+            actions[g] = kat["action"][i]
+        if (actions < 0).all():
+            break
+        batch.step(actions)
+    assert n_images > 100
+    batch.close()
+
+
+def test_device_search_on_per_game_maps_equals_the_reference():
+    """MCTS self-play, every game on its own map and one stream per game (map first): the games the genuine Explorer
+    played (scs_search_pergame_kat.json.gz) -- every root statistic of every move."""
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from test_gpu_scs import _host_evaluator
+    with gzip.open(os.path.join(GOLDEN, "scs_search_pergame_kat.json.gz"), "rt") as f:
+        kat = json.load(f)
+    for name, case in kat.items():
+        cfg = ScsGameConfig(PATH, per_game=True)
+        games = case["games"]
+        sp = ScsSelfPlay(cfg, case["config"], len(games), training=case["training"])
+        r = sp.play(_host_evaluator(cfg.num_actions), [g["seed"] for g in games])
+        for g, ref in enumerate(games):
+            assert np.array_equal(sp.game_maps[0][g].reshape(cfg.rows, cfg.cols, 3), np.array(ref["terrain"], np.float32))
+            assert r["lengths"][g] == ref["length"] and r["outcomes"][g] == ref["terminal_value"], (name, g)
+            for m, mv in enumerate(ref["moves"]):
+                k = len(mv["child_actions"])
+                assert r["actions"][g, m] == mv["action"], (name, g, m)
+                assert r["tree_size"][g, m] == mv["root_visits"] and r["n_children"][g, m] == k
+                assert r["bias"][g, m] == mv["bias"] and r["root_value_sum"][g, m] == mv["root_value_sum"]
+                assert r["child_action"][g, m, :k].tolist() == mv["child_actions"]
+                assert r["child_visit"][g, m, :k].tolist() == mv["child_visits"], (name, g, m)
+                assert r["child_prior"][g, m, :k].tolist() == mv["child_priors"], (name, g, m)
+                assert r["child_value_sum"][g, m, :k].tolist() == mv["child_value_sums"]
+        assert r["expansions"] == sum(g["evaluations"] for g in games)
+        sp.close()
+
+
+def _properties_on_own_maps(r, seeds, games):
+    """Replay through the oracle rules, every game on the map the oracle draws from its own seed."""
+    from oracle.scs import ScsConfig, ScsGame
+    for g in games:
+        og = ScsGame(ScsConfig(PATH, map_seed=np.random.RandomState(int(seeds[g]))))
+        n = int(r["lengths"][g])
+        for m in range(n):
+            legal = np.nonzero(og.possible_actions().reshape(-1))[0]
+            k = int(r["n_children"][g, m])
+            assert r["child_action"][g, m, :k].tolist() == legal.tolist(), (g, m)
+            assert int(r["child_visit"][g, m, :k].sum()) == int(r["tree_size"][g, m]) - 1, (g, m)
+            og.step_index(int(r["actions"][g, m]))
+        assert og.terminal and og.terminal_value == r["outcomes"][g], g
+
+
+def test_1024_different_maps_in_one_engine_both_routes_and_refill():
+    """The library's move loop with the native network, 1024 games on 1024 different maps: the persistent route and the
+    wave-by-wave route play the same games (bit for bit), a sample replays legally through the oracle on its own maps, and
+    a round of more games than trees (a tree's next game brings its own map) equals the same games one per tree."""
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    from test_gpu_scs_configs import a1_search, _net, _same_games
+    cfg = ScsGameConfig(PATH, per_game=True)
+    G = 1024
+    net, _ = _net(cfg, "convnet", 32, 3, seed=21, gain=2.0, max_batch=G)
+    search = a1_search(24)
+    seeds = list(range(9000, 9000 + G))
+    sp = ScsSelfPlay(cfg, search, G)
+    sp.persistent(1)
+    rp = sp.play_native(net, seeds)
+    assert sp.persistent() is True
+    assert len({t.tobytes() for t in sp.game_maps[0]}) > 1000
+    assert rp["simulations"] == 24 * int(rp["lengths"].sum())
+    _properties_on_own_maps(rp, seeds, range(0, G, 64))
+    sp.persistent(0)
+    rw = sp.play_native(net, seeds)
+    assert sp.persistent() is False
+    _same_games(rp, rw, [(g, g) for g in range(G)], "per-game maps")
+    sp.close()
+    small = ScsSelfPlay(cfg, search, 96)
+    rr = small.play_round(net, seeds[:300])
+    _same_games(rr, rp, [(g, g) for g in range(300)], "refill on own maps")
+    small.close(); net.close()

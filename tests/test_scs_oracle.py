@@ -122,3 +122,71 @@ def test_randomized_maps_against_reference():
             assert pc.vp.tolist() == [list(p) for side in want["vp"] for p in side]
             seen.add(json.dumps(want["terrain"]))
         assert len(seen) == len(cases)                        # the seeds give different maps
+
+
+def test_games_on_their_own_randomized_maps_against_reference():
+    """A new "Randomized" map per game (Gamer.py:52 builds a game object per game; SCS_Game.py:1678-1738 draws its map
+    at construction): 24 games the genuine SCS_Game played, each after np.random.seed(5000 + i) (scs_pergame_kat.npz,
+    tests/golden/make_golden_scs_pergame.py) -- the oracle on the map it draws from the same seed, step by step."""
+    kat = dict(np.load(os.path.join(GOLDEN, "scs_pergame_kat.npz")))
+    path = os.path.join(GOLDEN, "scs_configs", "randomized_5x5.yml")
+    planes, rows, cols, channels, stacking, turns = kat["shape"]
+    w = checksum_weights(channels * rows * cols)
+    images = {int(s): img for s, img in zip(kat["image_step"], kat["images"])}
+    game_ids, actions, legal, n_legal = kat["game"], kat["action"], kat["legal"], kat["n_legal"]
+    pos, g, last, n_images = 0, None, -1, 0
+
+    def end(gi, g):
+        assert g.is_terminal() and g.get_length() == kat["lengths"][gi] and g.get_terminal_value() == kat["values"][gi]
+        assert np.array_equal(g.state_image()[0], images[-(gi + 1)])
+
+    for i in range(len(actions)):
+        if game_ids[i] != last:
+            if g is not None:
+                end(last, g)
+            last = int(game_ids[i])
+            cfg = ScsConfig(path, map_seed=int(kat["map_seed"][last]))
+            assert np.array_equal(np.array(cfg.terrain, np.float64), kat["terrain"][last])
+            assert [[list(p) for p in side] for side in cfg.vp] == kat["vp"][last].tolist()
+            g = ScsGame(cfg)
+        assert (g.player, g.sub_phase, g.stage, g.turn) == (kat["player"][i], kat["sub_phase"][i], kat["stage"][i], kat["turn"][i]), i
+        idx = np.nonzero(g.possible_actions().flatten())[0]
+        assert idx.tolist() == legal[pos:pos + n_legal[i]].tolist(), i
+        pos += n_legal[i]
+        img = g.state_image()
+        assert float(np.sum(img.reshape(-1).astype(np.float64) * w)) == kat["checksum"][i], i
+        if i in images:
+            assert np.array_equal(img[0], images[i]), i
+            n_images += 1
+        g.step_index(int(actions[i]))
+    end(last, g)
+    assert n_images > 100 and len(set(kat["terrain"].reshape(24, -1).sum(1).tolist())) > 10
+
+
+def test_search_on_per_game_maps_against_reference():
+    """MCTS self-play where every game has its own map and ONE stream (np.random.seed(s); SCS_Game(config); play): the
+    oracle draws the map from RandomState(s) and its Explorer goes on with the same stream."""
+    import gzip
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from scs_eval import evaluate_image
+    from oracle import search as osearch
+    with gzip.open(os.path.join(GOLDEN, "scs_search_pergame_kat.json.gz"), "rt") as f:
+        kat = json.load(f)
+    path = os.path.join(GOLDEN, "scs_configs", "randomized_5x5.yml")
+    for name, case in kat.items():
+        for ref in case["games"]:
+            rs = np.random.RandomState(ref["seed"])
+            cfg = ScsConfig(path, map_seed=rs)
+            assert np.array_equal(np.array(cfg.terrain, np.float64), np.array(ref["terrain"]))
+            ev = lambda game: evaluate_image(game.state_image()[0], cfg.num_actions)
+            game = ScsGame(cfg)
+            trace = []
+            osearch.play_game(game, ev, case["config"], rs, training=case["training"], trace=trace)
+            assert game.length == ref["length"] and game.terminal_value == ref["terminal_value"], name
+            assert len(trace) == len(ref["moves"])
+            for mine, theirs in zip(trace, ref["moves"]):
+                for key in ("action", "root_visits", "root_value_sum", "child_actions", "child_visits", "child_priors",
+                            "child_value_sums"):
+                    assert mine[key] == theirs[key], (name, key)
