@@ -41,6 +41,9 @@ Extra keys (N = 1)
                     undisturbed launch
   scs_config4_round4  scs_config4 with four games per concurrent tree in one round (nz_scs_search_play_round: a tree
                     whose game has ended starts the round's next game)
+  scs_config5       BASELINE.json configs[4] on one GPU, bounded: SCS 10x10, RecurrentNet(256 x 2, recall) x 16 iterations,
+                    400 sims/move, 64 games x their first 2 decisions; expansions/s and the network's rate
+  ttt_config3_share BASELINE.json configs[2]'s share of one GPU: 1024 concurrent Tic-Tac-Toe games, 400 sims/move
   cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
                     Explorer/Gamer path) on this box's host cores, one process per core, on a bounded sample
 """
@@ -112,6 +115,50 @@ def launch_ranks(n):
     return subprocess.call(cmd)
 
 
+def live_traffic(args, n_round):
+    """HBM bytes per launch of the persistent kernel, measured NOW: two child processes under rocprofv3 (--pmc FETCH_SIZE
+    and --pmc WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes; the program itself right after `--`),
+    started before this process makes any GPU call.  None when rocprofv3 is not on PATH or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    vals = {}
+    cmd_tail = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+                "--games", str(args.games), "--round", str(n_round), "--sims", str(args.sims), "--iters", str(args.iters)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="nz_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + cmd_tail,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            got = []
+            with open(files[0]) as f:
+                rd = csv.reader(f)
+                head = next(rd)
+                kn, cn, cv = head.index("Kernel_Name"), head.index("Counter_Name"), head.index("Counter_Value")
+                for row in rd:
+                    if "selfplay_kernel<false>" in row[kn] and row[cn] == counter:
+                        got.append(float(row[cv]))
+            if not got:
+                return None
+            vals[counter] = sum(got) / len(got)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # KB units; on gfx950 FETCH_SIZE reports half the bytes of 16-B-per-lane reads (all of this kernel's reads): 2 F + W
+    return {"hbm_bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+            "how": "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate child processes, one launch each), "
+                   "2 x FETCH_SIZE + WRITE_SIZE"}
+
+
 def git_commit():
     try:
         return subprocess.check_output(["git", "-C", REPO, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL,
@@ -170,6 +217,74 @@ def scs_config4(device, games_per_tree=1):
                                        "flight per tree (Explorer.py:49-61), so a game's network pass runs on two wavefronts"}
     sp.close()
     net.close()
+    return out
+
+
+def scs_config5(device, games=64, moves=2):
+    """BASELINE.json configs[4] on one GPU, bounded: SCS 10x10 map, RecurrentNet(86 -> 21, 256 filters, 2 blocks, recall,
+    relu value head; Run.py:148) with 16 recurrent iterations, 400 simulations per move -- `games` games, the first
+    `moves` decisions of each (a whole game is ~120 decisions x 400 evaluations x 9 GFLOP).  Wave-by-wave route: the
+    per-layer board-net kernels (a 256-wide net on 100 cells has no one-launch form)."""
+    import torch
+    from nuzero_amd.boardnet import BoardNet
+    from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
+    from nuzero_amd.weights import synthetic_weights, recurrent_net_param_shapes
+    cfg = ScsGameConfig(os.path.join(REPO, "tests", "golden", "scs_configs", "ten_by_ten.yml"))
+    search = {"Simulation": {"mcts_simulations": 400, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
+              "Exploration": {"number_of_softmax_moves": 0, "epsilon_softmax_exploration": 0.04,
+                              "epsilon_random_exploration": 0.001, "value_factor": 1,
+                              "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
+                              "root_dist_alpha": 0.15, "root_dist_beta": 1}}
+    net = BoardNet("recurrent", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=256, num_blocks=2, recall=True,
+                   value_activation="relu", max_batch=games, device=device)
+    net.set_weights(synthetic_weights(0, recurrent_net_param_shapes(cfg.channels, cfg.planes, 256, 2, True)), 16)
+    sp = ScsSelfPlay(cfg, search, games, device=device)
+    sp.play_native(net, range(games), max_moves=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = sp.play_native(net, range(10 ** 5, 10 ** 5 + games), max_moves=moves)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tflops = r["expansions"] * net.flops_per_position / dt / 1e12
+    out = {"value": r["expansions"] / dt, "unit": "expansions/s", "simulations_per_s": r["simulations"] / dt,
+           "decisions_per_s": games * moves / dt, "seconds": dt, "waves": r["waves"],
+           "sample": "%d games x first %d decisions x 400 simulations" % (games, moves),
+           "net_flops_per_position": net.flops_per_position, "net_tflops_algorithmic_f32": tflops,
+           "net_frac_of_bf16_peak_as_issued": 6 * tflops / MFMA_BF16_PEAK_TFLOPS,
+           "note": "end to end (rules, tree, network); the 256-filter layers issue six bf16 MFMAs per float32 product, so the "
+                   "fraction of the BF16 peak as issued is 6 x the algorithmic rate / 2500",
+           "workload": "SCS 10x10 map (stack 2, 86 planes, 2100 actions), RecurrentNet(256 filters, 2 blocks, recall, relu "
+                       "value head) x 16 iterations, 400 sims/move, a1 search config, 1 GPU's share, bounded sample"}
+    sp.close()
+    net.close()
+    return out
+
+
+def ttt_config3_share(cfg_sims, weights, iters, device, games=1024, sims=400):
+    """BASELINE.json configs[2]'s share of one GPU: 8192 Tic-Tac-Toe games over 8 GPUs = 1024 concurrent games per GPU,
+    400 simulations per move, one round (one launch of the persistent kernel)."""
+    import torch
+    from nuzero_amd.engine import SelfPlayEngine
+    from nuzero_amd.search_config import legacy_ttt_search_config
+    eng = SelfPlayEngine(legacy_ttt_search_config(sims), games, training=True, device=device, n_slots=games)
+    eng.set_weights(weights, recurrent_iterations=iters)
+    eng.play(base_seed=8 * 10 ** 6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rounds, exp, sim = 3, 0, 0
+    for i in range(rounds):
+        eng.play(base_seed=8 * 10 ** 6 + (i + 1) * games)
+        c = eng.counters()
+        exp += c["expansions"]
+        sim += c["simulations"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"value": rounds * games / dt, "unit": "games/s", "expansions_per_s": exp / dt,
+           "simulations_per_s": sim / dt, "rounds": rounds, "games_per_round": games,
+           "sims_per_move": sims,
+           "note": "1024 games are 64 workgroups of 16: a quarter of the chip's CUs (one 16-game tile per CU)",
+           "workload": "Tic_Tac_Toe, 400 sims/move, 1024 concurrent games (one GPU's share of 8192 over 8 GPUs)"}
+    eng.close()
     return out
 
 
@@ -275,6 +390,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-kernel measurements after the timed steps")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short child runs under rocprofv3 --pmc); the "
+                         "stored measurement of profiles/ is quoted instead")
     ap.add_argument("--rounds-in-flight", type=int, default=0,
                     help="also measure the rounds with this many engines in flight (key rounds_in_flight_N); not part of "
                          "the default run: overlapped launches would spoil the kernel's average duration in a "
@@ -297,6 +415,10 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.sims, args.cpu_seconds)
+    # ... and so do the two counter passes for roofline.traffic (child processes under rocprofv3)
+    traffic_live = None
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_live_traffic:
+        traffic_live = live_traffic(args, n_round)
 
     import torch
     from nuzero_amd.engine import SelfPlayEngine
@@ -413,14 +535,21 @@ def main():
         # HBM bytes per launch from PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs, corrected as the
         # guide prescribes): a stored measurement, quoted with its commit, only for the configuration it was made on
         traffic = traffic_at = None
-        tpath = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("config") == [args.games, n_round, args.sims, args.iters]:
-                traffic, traffic_at = tj["hbm_bytes_per_launch"], tj.get("commit")
+        if traffic_live is not None:
+            traffic, traffic_at = traffic_live["hbm_bytes_per_launch"], "this run"
+        else:
+            for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+                tpath = os.path.join(REPO, "profiles", name)
+                if os.path.exists(tpath):
+                    with open(tpath) as f:
+                        tj = json.load(f)
+                    if tj.get("config") == [args.games, n_round, args.sims, args.iters]:
+                        traffic, traffic_at = tj["hbm_bytes_per_launch"], "stored: profiles/%s at commit %s" % (name, tj.get("commit"))
+                        break
         out["roofline"] = mfma_roofline("selfplay_kernel (persistent: tree phases + fused RecurrentNet forward)",
                                         pc["expansions"], k_ms, k_n, traffic, traffic_at)
+        if traffic_live is not None:
+            out["roofline"]["traffic_detail"] = traffic_live
 
         # ---- in-kernel phase shares (stamped diagnostic build; its run time is only used for the tree-phase figure)
         eng.phase_stamps(True)
@@ -518,6 +647,8 @@ def main():
             out[key]["vs_round_4x"] = out[key]["value"] / out["round_4x"]["value"]
         out["scs_config4"] = scs_config4(local_rank)
         out["scs_config4_round4"] = scs_config4(local_rank, games_per_tree=4)
+        out["scs_config5"] = scs_config5(local_rank)
+        out["ttt_config3_share"] = ttt_config3_share(cfg, weights, args.iters, local_rank)
 
     if rank == 0:
         if cpu is not None:
