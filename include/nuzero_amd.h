@@ -487,10 +487,6 @@ nz_rng* nz_rng_create(uint32_t seed);
 /* a stream that goes on where a numpy RandomState stands (RandomState.get_state(): key[624], pos, has_gauss, cached_gaussian) */
 nz_rng* nz_rng_create_state(const uint32_t* key624, int32_t pos, int32_t has_gauss, double cached_gaussian);
 nz_rng* nz_rng_clone(const nz_rng* r);
-/* Host-side proof obligation of the tree kernels' select arithmetic: sqrt(N) / (n + 1) is computed there as
- * q0 = sqrt(N) * r, q = fma(fma(-(n + 1), q0, sqrt(N)), r, q0) with r = 1.0 / (n + 1) stored per node.  Checks every
- * N < tab_len, n <= N against the IEEE quotient; returns the number of mismatches (0: identical on the whole table). */
-int64_t nz_check_division_by_reciprocal(int32_t tab_len);
 void nz_rng_destroy(nz_rng* r);
 void nz_rng_seed(nz_rng* r, uint32_t seed);
 uint32_t nz_rng_u32(nz_rng* r);

@@ -155,7 +155,6 @@ SIGNATURES = {
     "nz_rng_create": (c_void_p, [c_uint32]),
     "nz_rng_create_state": (c_void_p, [c_void_p, c_int32, c_int32, c_double]),
     "nz_rng_clone": (c_void_p, [c_void_p]),
-    "nz_check_division_by_reciprocal": (c_int64, [c_int32]),
     "nz_rng_destroy": (None, [c_void_p]),
     "nz_rng_seed": (None, [c_void_p, c_uint32]),
     "nz_rng_u32": (c_uint32, [c_void_p]),

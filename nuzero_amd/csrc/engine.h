@@ -32,10 +32,7 @@ struct __attribute__((aligned(16))) TNode {
   int32_t visit;
   uint32_t first;         // index of the first child
   uint32_t meta;          // packed: see pack_meta
-  uint32_t pad;
-  double rcp;             // 1.0 / (visit + 1), correctly rounded; rewritten by every backup: select divides sqrt(N) by
-                          // (visit + 1) for every child of every level, and with the reciprocal at hand the IEEE quotient is
-                          // one multiplication and two fused multiply-adds (div_by_rcp, tree_dev.hpp)
+  uint32_t pad[3];
 };
 static_assert(sizeof(TNode) == 48, "three 16-byte loads per node");
 

@@ -157,22 +157,3 @@ void nz_rng_gamma(nz_rng* r, double shape, double scale, int32_t n, double* out)
 }
 
 }  // extern "C"
-
-// Exhaustive proof for tree_dev.hpp div_by_rcp: over every N < tab_len and every b = 1 .. N + 1, with a = sqrt(N) as the
-// visit table holds it and r = 1.0 / b, the multiply + two fused multiply-adds equal the IEEE quotient a / b bit for
-// bit.  Returns the number of operand pairs for which they do not (0 = proven for this table).
-extern "C" int64_t nz_check_division_by_reciprocal(int32_t tab_len) {
-  int64_t bad = 0;
-  for (int N = 0; N < tab_len; ++N) {
-    const double a = std::sqrt((double)N);
-    for (int bi = 1; bi <= N + 1; ++bi) {
-      const double b = (double)bi, r = 1.0 / b;
-      const double q0 = a * r;
-      const double e = std::fma(-b, q0, a);
-      const double q = std::fma(e, r, q0);
-      const double ref = a / b;
-      if (!(q == ref)) ++bad;
-    }
-  }
-  return bad;
-}

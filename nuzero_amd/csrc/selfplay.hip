@@ -106,7 +106,6 @@ __device__ __forceinline__ void unpark(RowState& s, RootCache& rc, int32_t (*row
   rc.n = lane[4][tid];
   rc.vs = __hiloint2double(lane[6][tid], lane[5][tid]);
   rc.q = __hiloint2double(lane[8][tid], lane[7][tid]);
-  rc.rcp = 1.0 / (double)(rc.n + 1);            // (not parked: one division per lane and phase)
   rc.pr = __hiloint2double(lane[10][tid], lane[9][tid]);
   rc.lk = make_uint2((uint32_t)lane[11][tid], (uint32_t)lane[12][tid]);
   (void)sub;

@@ -106,8 +106,7 @@ __device__ __forceinline__ TNode fresh_node(uint32_t action) {
   TNode n;
   n.value_sum = 0.0; n.q = 0.0; n.prior = 0.0; n.visit = 0; n.first = 0u;
   n.meta = pack_meta(0u, action, TO_PLAY_UNSET, 0u);
-  n.pad = 0u;
-  n.rcp = 1.0;
+  n.pad[0] = n.pad[1] = n.pad[2] = 0u;
   return n;
 }
 __device__ __forceinline__ void arena_reset(Arena t) { t[0] = fresh_node(0u); }   // Node(0), Gamer.py:59
@@ -133,9 +132,8 @@ __device__ __forceinline__ int expand_row(const TreeParams& p, Arena t, int leaf
   }
   if (legal) {
     const int c = base + __popc(empty & ((1u << sub) - 1u));
-    t[c].value_sum = 0.0;                     // (the padding word is never read: not written either)
+    t[c].value_sum = 0.0;                     // (the three padding words are never read: not written either)
     t[c].q = 0.0;
-    t[c].rcp = 1.0;
     t[c].prior = pd / total;
     t[c].visit = 0;
     t[c].first = 0u;
@@ -156,26 +154,14 @@ __device__ __forceinline__ void backup_row(Arena t, int my_node, int path_len, d
     t[my_node].visit = n;
     t[my_node].value_sum = vs;
     t[my_node].q = vs / (double)n;
-    t[my_node].rcp = 1.0 / (double)(n + 1);
   }
 }
 
 // PUCT score of one child (Explorer.py:103-130), shared by both descents.  `q` is the child's stored
 // value_sum / visit_count (0.0 while unvisited, Node.py:19-22).
-// a / b for b = a small positive integer, given r = 1.0 / b correctly rounded: q0 = a * r is within an ulp of the
-// quotient, the residual a - b * q0 is exact in one fused multiply-add, and the correction q0 + residual * r rounds to
-// the IEEE quotient (Markstein's division step).  For this table of operands -- a = sqrt(N), b = n + 1 <= N + 1, N below
-// the visit table's length -- the identity with `a / b` is checked exhaustively on the host
-// (nz_check_division_by_reciprocal, tests/test_rng_host.py).  The file is compiled -ffp-contract=off: the two fma are
-// the only fused operations.
-__device__ __forceinline__ double div_by_rcp(double a, double b, double r) {
-  const double q0 = a * r;
-  const double e = __builtin_fma(-b, q0, a);
-  return __builtin_fma(e, r, q0);
-}
 __device__ __forceinline__ double puct_score(const TreeParams& p, double sq, double cb, bool negate, int n, double q,
-                                             double pr, double rcp) {
-  const double u = div_by_rcp(sq, (double)(n + 1), rcp);
+                                             double pr) {
+  const double u = sq / (double)(n + 1);
   double conf = pr * u;
   conf = conf * cb;
   if (negate) q = -q;
@@ -250,7 +236,7 @@ __device__ __forceinline__ Descent descend_row(const TreeParams& p, Arena t, int
       const TNode c = t[base + sub];
       n = c.visit;
       clk = make_uint2(c.first, c.meta);
-      score = puct_score(p, sq, cb, negate, n, c.q, c.prior, c.rcp);
+      score = puct_score(p, sq, cb, negate, n, c.q, c.prior);
     }
     const int win = row_argmax(score, sub);
     clk.x = (uint32_t)row_geti((int)clk.x, win);
@@ -279,7 +265,7 @@ struct RootCache {
   double root_vs;
   uint32_t root_meta;
   int n;                 // lane j < k: child j
-  double vs, q, pr, rcp;
+  double vs, q, pr;
   uint2 lk;
 };
 __device__ __forceinline__ void root_cache_load(RootCache& c, Arena t, int root, int sub) {
@@ -293,14 +279,12 @@ __device__ __forceinline__ void root_cache_load(RootCache& c, Arena t, int root,
   c.vs = 0.0;
   c.q = 0.0;
   c.pr = 0.0;
-  c.rcp = 1.0;
   c.lk = make_uint2(0u, 0u);
   if (sub < c.k) {
     const TNode ch = t[c.base + sub];
     c.n = ch.visit;
     c.vs = ch.value_sum;
     c.q = ch.q;
-    c.rcp = ch.rcp;
     c.pr = ch.prior;
     c.lk = make_uint2(ch.first, ch.meta);
   }
@@ -348,15 +332,15 @@ __device__ __forceinline__ Descent descend_cached(const TreeParams& p, Arena t, 
     double vs = 0.0;
     uint2 clk = make_uint2(0u, 0u);
     if (sub < k) {
-      double pr, q, rcp;
+      double pr, q;
       if (d.path_len == 1) {          // children of the root: registers
-        n = c.n; vs = c.vs; q = c.q; pr = c.pr; rcp = c.rcp; clk = c.lk;
+        n = c.n; vs = c.vs; q = c.q; pr = c.pr; clk = c.lk;
       } else {
         const TNode ch = t[base + sub];
-        n = ch.visit; vs = ch.value_sum; q = ch.q; pr = ch.prior; rcp = ch.rcp;
+        n = ch.visit; vs = ch.value_sum; q = ch.q; pr = ch.prior;
         clk = make_uint2(ch.first, ch.meta);
       }
-      score = puct_score(p, sq, cb, negate, n, q, pr, rcp);
+      score = puct_score(p, sq, cb, negate, n, q, pr);
     }
     const int win = row_argmax(score, sub);
     if (d.path_len == 1) win0 = win;
@@ -384,7 +368,6 @@ __device__ __forceinline__ void backup_cached(Arena t, RootCache& c, int my_node
     t[my_node].visit = my_n + 1;
     t[my_node].value_sum = vs;
     t[my_node].q = vs / (double)(my_n + 1);
-    t[my_node].rcp = 1.0 / (double)(my_n + 2);
   }
   c.root_n += 1;
   c.root_vs = c.root_vs + value;
@@ -392,7 +375,6 @@ __device__ __forceinline__ void backup_cached(Arena t, RootCache& c, int my_node
     c.n += 1;
     c.vs = c.vs + value;
     c.q = c.vs / (double)c.n;
-    c.rcp = 1.0 / (double)(c.n + 1);
   }
 }
 

@@ -102,12 +102,3 @@ def test_pairwise_order():
             for _ in range(50):
                 a = (rs.uniform(0, 1, n) ** 8).astype(dt)
                 assert np.sum(a) == pw(a)
-
-
-def test_division_by_stored_reciprocal_is_the_ieee_quotient():
-    """Select computes sqrt(N) / (n + 1) (Explorer.py:114-116) from the node's stored 1 / (n + 1): one multiplication and two
-    fused multiply-adds (tree_dev.hpp div_by_rcp).  Exhaustive over the visit tables of 100 and 400 simulations per move
-    (N < sims * 9 + 2, every n <= N): identical to the IEEE division, bit for bit."""
-    from nuzero_amd._lib import lib
-    assert lib.nz_check_division_by_reciprocal(100 * 9 + 2) == 0
-    assert lib.nz_check_division_by_reciprocal(400 * 9 + 2) == 0
