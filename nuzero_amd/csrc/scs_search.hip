@@ -93,7 +93,8 @@ struct SearchParams {
   uint64_t* c_id;          // [entries][2] the 128-bit hash of the state an entry holds (0, 0: empty)
   float* c_probs;          // [entries][A] post-softmax probabilities
   float* c_value;          // [entries]
-  int32_t* c_writer;       // [entries] last wave that wrote the entry
+  int32_t* c_writer;       // [entries] last wave that wrote the entry (wave-by-wave route)
+  uint64_t* c_check;       // [entries] check word over (key, probabilities, value) (persistent route: self-validating entries)
   uint64_t* leaf_key;      // [G][2] hash of each queued (missed) leaf, by evaluation slot
   int32_t* hit_count;      // [1] hits of this wave
   float* eval_probs;       // [3 G][A] evaluations: the network's [0, G), cache hits [G, 2 G) / [2 G, 3 G) by wave parity
@@ -362,6 +363,12 @@ __device__ __forceinline__ void state_hash_wave(const ScsState& st, int lane, ui
   hi = mix64(a ^ (b >> 7));
   lo = mix64(b ^ (a << 9));
   if (hi == 0 && lo == 0) lo = 1;                                 // (0, 0) marks an empty entry
+}
+__global__ void cache_count_kernel(const uint64_t* __restrict__ c_id, int64_t entries, int64_t* __restrict__ out) {
+  long long n = 0;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < entries; e += (int64_t)gridDim.x * blockDim.x)
+    n += (c_id[2 * e] != 0 || c_id[2 * e + 1] != 0) ? 1 : 0;
+  if (n) atomicAdd((unsigned long long*)out, (unsigned long long)n);
 }
 // After the network: the wave's evaluated leaves go into the table (KeylessCache.put: the newest entry replaces
 // what the slot held).  One wavefront per leaf; of two leaves of the same wave that map to the same entry the first
@@ -741,6 +748,12 @@ __device__ __forceinline__ void image_hash_wave(const float* stage, int inp, int
   lo = mix64(b ^ (a << 9));
 }
 
+// the check word of a cache entry: per-lane sums of per-probability mixes (acc), the value and the key
+__device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, uint64_t key_hi, uint64_t key_lo) {
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor((unsigned long long)acc, o, 64);
+  return mix64(acc ^ mix64(key_hi ^ (uint64_t)__builtin_bit_cast(uint32_t, value)) ^ (key_lo * 0xd6e8feb86659fd93ull));
+}
+
 // One conv layer's K loop for one position and ONE column tile: both row tiles (25 cells), NTAPS x KGT steps as
 // straight-line code.  Activations (the MFMA's second operand) come from LDS, this lane's operand row per tap in srow,
 // read one step ahead of the MFMAs that use them; the weights (first operand) straight from the packed L2 stream, their
@@ -1005,7 +1018,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   const int pol_off = PHDR(pol_off), pp = PHDR(pol_cs), val_off = PHDR(val_off), vp = PHDR(val_cs);
 #undef PHDR
   scs_sync<false>();
-  unsigned long long n_sim = 0, n_exp = 0;
+  unsigned long long n_sim = 0, n_exp = 0, n_hit = 0, n_miss = 0;
   bool failed = false;
 #ifdef NZ_PERSIST_STAMPS   // diagnostic build: where a game's time goes (nz_scs_search_persist_ticks)
   unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
@@ -1118,12 +1131,72 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         break;
       }
       PSTAMP(2);                                // legal mask + list
+      float* const pol = net + pol_off;
+      // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
+      const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
+      float sum = 1.0f, value = 0.f;
+      // The inference cache (Explorer.py:146-155): the table is shared by every game of the engine and, on this route, read
+      // and written while the kernel runs -- by games on all eight XCDs, so every access is an agent-scope atomic (past this
+      // CU's L1 and this XCD's L2) and there are no fences (agent-scope fences write back / invalidate whole caches: 817
+      // games/s with them against 970 without a cache).  Entries validate themselves: next to the state's 128-bit key an
+      // entry holds a 64-bit check word over (key, probabilities, value); a reader takes everything in ONE round of loads
+      // and accepts it only if the key is its leaf's and the check word fits what it read -- an entry caught half
+      // written, or written by two games at once, fails and counts as a miss.  Writers just store (newest wins,
+      // KeylessCache.py:60-75).  A hit is the evaluation the network made for the same state: the search cannot tell.
+      uint64_t key_hi = 0, key_lo = 0;
+      size_t entry = 0;
+      bool hit = false;
+      if (p.c_bits > 0) {
+        state_hash_wave(sc, lane, key_hi, key_lo);
+        entry = (size_t)(key_lo & ((1ull << p.c_bits) - 1));
+        unsigned long long* const id = reinterpret_cast<unsigned long long*>(p.c_id + 2 * entry);
+        const unsigned long long id0 = __hip_atomic_load(id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long id1 = __hip_atomic_load(id + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long chk = __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.c_check + entry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float cval = __hip_atomic_load(p.c_value + entry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t acc = 0;
+        {   // (all of a block's loads in flight together: one round trip to memory, not one per probability)
+          constexpr int PER = 12;
+          int cell = cell0, plane = plane0;
+          for (int i0 = 0; i0 < A; i0 += 64 * PER) {
+            float r[PER];
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+              const int i = i0 + j * 64 + lane;
+              r[j] = i < A ? __hip_atomic_load(p.c_probs + entry * A + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+              const int i = i0 + j * 64 + lane;
+              if (i < A) {
+                pol[cell * pp + plane] = r[j];
+                acc += mix64((((uint64_t)(uint32_t)i << 32) | __builtin_bit_cast(uint32_t, r[j])) ^ 0x9e3779b97f4a7c15ull);
+              }
+              cell += dcell; plane += dplane;
+              if (cell >= hw) { cell -= hw; ++plane; }
+            }
+          }
+        }
+        hit = id0 == key_hi && id1 == key_lo && cache_check_word(acc, cval, key_hi, key_lo) == chk;     // (uniform)
+        if (hit) { value = cval; ++n_hit; } else ++n_miss;
+        scs_sync<false>();
+      }
+      uint64_t dig_hi = 0, dig_lo = 0;
+      if (hit && rec >= 0) {                    // (the test hook records every evaluation the search consumed: the planes' digest)
+        float* const stage = net + q.stage_off;
+        scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
+        scs_sync<false>();
+        image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
+        scs_sync<false>();
+        for (int i = lane * 4; i < q.stage_floats; i += 256) *reinterpret_cast<f32x4*>(stage + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        scs_sync<false>();
+      }
+      if (!hit) {
       // the leaf's planes (generate_network_input, SCS_Game.py:1507): float32 rows over the trunk buffers' space, split
       // into the input pieces, then that space is zeros again (the buffers' rows of zeros, channels no layer writes)
       float* const stage = net + q.stage_off;
       scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
       scs_sync<false>();
-      uint64_t dig_hi = 0, dig_lo = 0;
       if (rec >= 0) image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
       {
         const int chunks = q.inp >> 3;
@@ -1161,9 +1234,6 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       PSTAMP(4);                                // network
 
       // softmax over ALL logits (Explorer.py:158-160) and value = tanh(mean of the value plane) (blocks.py:82-84)
-      float* const pol = net + pol_off;
-      // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
-      const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
       float mx = -INFINITY;
       for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
         mx = fmaxf(mx, pol[cell * pp + plane]);
@@ -1191,7 +1261,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
           }
         }
       }
-      float sum = 0.f;
+      sum = 0.f;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
         float ps = part[sub];
@@ -1200,11 +1270,31 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       }
       float sv = lane < hw ? net[val_off + lane * vp] : 0.f;
       for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w, 64);
-      const float value = tanhf(sv / (float)hw);
-      v = (double)value;
+      value = tanhf(sv / (float)hw);
       (void)planes;
       scs_sync<false>();
       PSTAMP(5);                                // softmax + value
+      if (p.c_bits > 0) {
+        // KeylessCache.put (KeylessCache.py:60-75): the newest evaluation takes the entry; stores only, nothing to wait for
+        unsigned long long* const id = reinterpret_cast<unsigned long long*>(p.c_id + 2 * entry);
+        uint64_t acc = 0;
+        for (int i = lane, cell = cell0, plane = plane0; i < A; i += 64) {
+          const float pr = pol[cell * pp + plane] / sum;
+          __hip_atomic_store(p.c_probs + entry * A + i, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          acc += mix64((((uint64_t)(uint32_t)i << 32) | __builtin_bit_cast(uint32_t, pr)) ^ 0x9e3779b97f4a7c15ull);
+          cell += dcell; plane += dplane;
+          if (cell >= hw) { cell -= hw; ++plane; }
+        }
+        const unsigned long long chk = cache_check_word(acc, value, key_hi, key_lo);
+        if (lane == 0) {
+          __hip_atomic_store(p.c_value + entry, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(id, (unsigned long long)key_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(id + 1, (unsigned long long)key_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.c_check + entry), chk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      }   // (!hit)
+      v = (double)value;
       if (rec >= 0) {
         if (rec_n < q.rec_cap) {
           const size_t at = (size_t)rec * q.rec_cap + rec_n;
@@ -1290,6 +1380,8 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
     if (rec >= 0) q.rec_count[rec] = rec_n;
     if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], n_sim);
     if (n_exp) atomicAdd((unsigned long long*)&p.counters[1], n_exp);
+    if (n_hit) atomicAdd((unsigned long long*)&p.counters[8], n_hit);
+    if (n_miss) atomicAdd((unsigned long long*)&p.counters[9], n_miss);
   }
 }
 
@@ -1539,6 +1631,7 @@ struct nz_scs_search {
   int cache_bits = 0;
   int64_t cache_entries = 0;
   int32_t cache_wave = 0;
+  int cache_route = 0;                        // which route filled the table (1 wave by wave, 2 persistent); they do not mix
   // persistent route (persist_kernel): -1 follow the default (on where the network has a per-wavefront form), 0 off, 1 on
   int persist_mode = -1;
   int persist_used = 0;                       // the last play ran on it
@@ -1746,7 +1839,7 @@ void nz_scs_search_destroy(nz_scs_search* h) {
     for (void* q : store)
       if (q) (void)hipFree(q);
   }
-  if (h->p.c_id) { (void)hipFree(h->p.c_id); (void)hipFree(h->p.c_probs); (void)hipFree(h->p.c_value); (void)hipFree(h->p.c_writer); }
+  if (h->p.c_id) { (void)hipFree(h->p.c_id); (void)hipFree(h->p.c_probs); (void)hipFree(h->p.c_value); (void)hipFree(h->p.c_writer); (void)hipFree(h->p.c_check); }
   if (h->rec_slot_dev) {
     (void)hipFree(h->rec_slot_dev); (void)hipFree(h->pq.rec_count); (void)hipFree(h->pq.rec_digest);
     (void)hipFree(h->pq.rec_probs); (void)hipFree(h->pq.rec_value);
@@ -1923,8 +2016,7 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
                     dalloc(h, &h->noise, (size_t)G * MAXC) && dalloc(h, &h->uniforms, (size_t)G * 3);
     if (!ok) return sfail(h, NZ_ERR_HIP, "device allocation failed");
   }
-  // the persistent route: the network must have a per-wavefront form and the inference cache must be off (the table is
-  // only ever written between two launches)
+  // the persistent route: the network must have a per-wavefront form
   bool persist = false;
   size_t persist_lds = 0;
   h->persist_used = 0;
@@ -1934,7 +2026,6 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     nz::WaveNet wn{};
     std::string why;
     if (mode == 0) h->persist_why = "switched off";
-    else if (h->cache_bits > 0) h->persist_why = "the inference cache is on";
     else if (!nz::boardnet_wave_program(net, &wn, &why)) h->persist_why = why;
     else {
       PersistArgs& q = h->pq;
@@ -1958,6 +2049,17 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     if (h->rec_slot_dev && !persist) return sfail(h, NZ_ERR_STATE, "leaf recording needs the persistent route: %s", h->persist_why.c_str());
   }
   h->pq.rec_slot = h->rec_slot_dev;
+  if (h->cache_bits > 0 && h->cache_route != (persist ? 2 : 1)) {
+    // the two routes keep their entries differently (check words / writer serial numbers): a table filled by the other
+    // one starts empty
+    if (h->cache_route != 0) {
+      const size_t n = (size_t)h->cache_entries;
+      S_HIP(h, hipMemsetAsync(h->p.c_id, 0, n * 2 * sizeof(uint64_t), (hipStream_t)stream));
+      S_HIP(h, hipMemsetAsync(h->p.c_writer, 0, n * sizeof(int32_t), (hipStream_t)stream));
+      S_HIP(h, hipMemsetAsync(h->p.c_check, 0, n * sizeof(uint64_t), (hipStream_t)stream));
+    }
+    h->cache_route = persist ? 2 : 1;
+  }
   std::vector<nz_rng*> rngs;
   struct RngGuard {
     std::vector<nz_rng*>& v;
@@ -2225,8 +2327,8 @@ nz_status nz_scs_search_cache(nz_scs_search* h, int64_t max_entries) {
   SearchParams& p = h->p;
   const size_t A = (size_t)p.num_actions;
   if (max_entries >= 0) {
-    if (p.c_id) { (void)hipFree(p.c_id); (void)hipFree(p.c_probs); (void)hipFree(p.c_value); (void)hipFree(p.c_writer); }
-    p.c_id = nullptr; p.c_probs = nullptr; p.c_value = nullptr; p.c_writer = nullptr;
+    if (p.c_id) { (void)hipFree(p.c_id); (void)hipFree(p.c_probs); (void)hipFree(p.c_value); (void)hipFree(p.c_writer); (void)hipFree(p.c_check); }
+    p.c_id = nullptr; p.c_probs = nullptr; p.c_value = nullptr; p.c_writer = nullptr; p.c_check = nullptr;
     h->cache_bits = 0; h->cache_entries = 0;
     if (max_entries == 0) return NZ_OK;
     int bits = 0;
@@ -2234,7 +2336,8 @@ nz_status nz_scs_search_cache(nz_scs_search* h, int64_t max_entries) {
     if (bits == 0) bits = 1;
     const size_t n = (size_t)1 << bits;
     if (hipMalloc((void**)&p.c_id, n * 2 * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&p.c_probs, n * A * sizeof(float)) != hipSuccess ||
-        hipMalloc((void**)&p.c_value, n * sizeof(float)) != hipSuccess || hipMalloc((void**)&p.c_writer, n * sizeof(int32_t)) != hipSuccess)
+        hipMalloc((void**)&p.c_value, n * sizeof(float)) != hipSuccess || hipMalloc((void**)&p.c_writer, n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void**)&p.c_check, n * sizeof(uint64_t)) != hipSuccess)
       return sfail(h, NZ_ERR_HIP, "cache allocation failed (%zu entries of %zu actions)", n, A);
     h->cache_bits = bits;
     h->cache_entries = (int64_t)n;
@@ -2243,6 +2346,7 @@ nz_status nz_scs_search_cache(nz_scs_search* h, int64_t max_entries) {
     const size_t n = (size_t)h->cache_entries;
     S_HIP(h, hipMemset(p.c_id, 0, n * 2 * sizeof(uint64_t)));
     S_HIP(h, hipMemset(p.c_writer, 0, n * sizeof(int32_t)));
+    S_HIP(h, hipMemset(p.c_check, 0, n * sizeof(uint64_t)));
     S_HIP(h, hipMemset(p.counters + 8, 0, 3 * sizeof(int64_t)));
     h->cache_wave = 0;
   }
@@ -2256,6 +2360,12 @@ nz_status nz_scs_search_cache_stats(nz_scs_search* h, int64_t* out4_host) {
   S_HIP(h, hipDeviceSynchronize());
   S_HIP(h, hipMemcpy(out4_host, h->p.counters + 8, 3 * sizeof(int64_t), hipMemcpyDeviceToHost));
   out4_host[3] = h->cache_entries;
+  if (h->cache_bits > 0) {      // entries in use: counted on the table itself (the persistent route's writers keep no count)
+    S_HIP(h, hipMemset(h->p.counters + 10, 0, sizeof(int64_t)));
+    hipLaunchKernelGGL(cache_count_kernel, dim3(256), dim3(256), 0, nullptr, h->p.c_id, h->cache_entries, h->p.counters + 10);
+    S_HIP(h, hipDeviceSynchronize());
+    S_HIP(h, hipMemcpy(out4_host + 2, h->p.counters + 10, sizeof(int64_t), hipMemcpyDeviceToHost));
+  }
   return NZ_OK;
 }
 
