@@ -773,7 +773,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_weights_rsrc(const uint32
 }
 __device__ __forceinline__ u32x4 wave_weights_load(__amdgpu_buffer_rsrc_t rs, int voff, int st, int piece) {
 #ifdef NZ_ABL_PERSIST_NOB      // timing experiment: no weight stream (results wrong)
-  return u32x4{(uint32_t)voff, (uint32_t)st, (uint32_t)piece, 0u};
+  return u32x4{(uint32_t)(voff & 0), (uint32_t)(st & 0), (uint32_t)(piece & 0), 0u};       // (zeros: finite activations)
 #else
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (st * 3 + piece) * 1024, 0));
 #endif
@@ -784,24 +784,24 @@ __device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1
 #pragma unroll
     for (int piece = 0; piece < 3; ++piece) bq[st][piece] = wave_weights_load(rs, voff, st, piece);
 }
-template <int NTAPS, int KGT>
-__device__ __forceinline__ void wave_conv(f32x4 (&acc)[2], const float* __restrict__ net, const int (&srow)[2][NTAPS],
+template <int NTAPS, int KGT, int RT = 2>
+__device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restrict__ net, const int (&srow)[RT][NTAPS],
                                           int off0, int cs0, int ps0, int kq, __amdgpu_buffer_rsrc_t wrs, int voff,
                                           u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
   constexpr int STEPS = NTAPS * KGT;
   constexpr int AHEAD = WAVE_AHEAD;
   static_assert(STEPS >= AHEAD, "the prologue is always AHEAD steps");
-  u32x4 a[2][2][3];
-  auto load_a = [&](int st, u32x4 (&dst)[2][3]) {
+  u32x4 a[2][RT][3];
+  auto load_a = [&](int st, u32x4 (&dst)[RT][3]) {
     const int tap = st / KGT, kg = st - tap * KGT;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int r = srow[rt][tap];
       const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
 #pragma unroll
       for (int piece = 0; piece < 3; ++piece) {
 #ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
-        dst[rt][piece] = u32x4{(uint32_t)a0, (uint32_t)piece, 0u, 0u};
+        dst[rt][piece] = u32x4{(uint32_t)(a0 & 0), (uint32_t)(piece & 0), 0u, 0u};
 #else
         dst[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
 #endif
@@ -817,8 +817,13 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[2], const float* __restri
       for (int piece = 0; piece < 3; ++piece)
         bq[(st + AHEAD) % (AHEAD + 1)][piece] = wave_weights_load(wrs, voff, st + AHEAD, piece);
     }
+#ifdef NZ_ABL_PERSIST_EARLYLDS
+    // experiment (not kept): force the next step's operand reads out BEFORE this step's MFMAs -- the pass alone 86.7 k
+    // ticks against 81.9 k, the round 775 against 970 games/s (longer live ranges, 54 spilled registers)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
+    for (int rt = 0; rt < RT; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
     __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
   }
 }
@@ -828,6 +833,9 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
                                               int lane, int rows) {
   const int orow = rt * 16 + (lane & 15), c0 = ct * 16 + (lane >> 4) * 4;
   if (orow >= rows) return;
+#ifdef NZ_ABL_PERSIST_NOEPI   // timing experiment: no epilogue (results wrong)
+  if (acc[0] != 12345.678f) return;
+#endif
   const int chunk = (((c0 >> 3) ^ ((orow >> 2) & 3)) << 2) + ((c0 & 7) >> 1);
   float v[4];
 #pragma unroll
@@ -872,11 +880,11 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
   }
 }
 
-template <int NTAPS, int KGT>
-__device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[2], const float* __restrict__ net, const Fused16Op& op,
-                                                 const int (&srow)[2][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
+template <int NTAPS, int KGT, int RT = 2>
+__device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* __restrict__ net, const Fused16Op& op,
+                                                 const int (&srow)[RT][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (an opaque k-quarter: the operand addresses of every step of every variant are loop-invariant arithmetic, and hoisted
   // out of the layer loop they are 180 live registers)
   int kq = lane >> 4;
@@ -886,7 +894,7 @@ __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[2], const float* _
 #if !NZ_PERSIST_XOP
   wave_weights_prologue(bq, wrs, voff);
 #endif
-  wave_conv<NTAPS, KGT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, voff, bq);
+  wave_conv<NTAPS, KGT, RT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, voff, bq);
 }
 
 // The two wavefronts of a game meet (the leader runs the tree and half of every layer, the helper the other half): each
@@ -984,7 +992,8 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
 // the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
 template <bool HEX>
 __device__ __forceinline__ void persist_leader(const SearchParams& p, const PersistArgs& q, const ScsRules& R, unsigned char* wb,
-                                               int g, int lane, int* flags, int* go) {
+                                               int g, const int lane_in, int* flags, int* go) {
+  int lane = lane_in;
   ScsState& real_l = *reinterpret_cast<ScsState*>(wb);
   ScsState& sc = *reinterpret_cast<ScsState*>(wb + PERSIST_STATE_BYTES);
   uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
@@ -1029,6 +1038,10 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
 #endif
 
   while (sims_left > 0) {
+    // (an opaque lane id per simulation: what is derived from it is a few cheap instructions, and carried around the
+    // whole loop instead it is a dozen registers spilled to scratch and reloaded in the middle of the tree phase)
+    lane = lane_in;
+    asm volatile("" : "+v"(lane));
     {   // scratch_game = game.shallow_clone()
       const uint32_t* src = reinterpret_cast<const uint32_t*>(&real_l);
       uint32_t* dst = reinterpret_cast<uint32_t*>(&sc);
@@ -1438,6 +1451,89 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   }
 }
 
+// ---- prototype (diagnostic only): FOUR wavefronts per game, one (row tile, column tile) each ------------------------
+__device__ __forceinline__ void quad_sync(int* flags, int me, int& seq, int lane) {
+  ++seq;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int o = 0; o < 4; ++o)
+    while (__hip_atomic_load(&flags[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool HEX>
+__device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
+                                             int H, int Wd, int lane, int quad, int* flags, int& seq) {
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int rt = quad & 1, half = quad >> 1;
+  int srow[1][ntaps];
+  {
+    const int row = rt * 16 + (lane & 15);
+    const bool row_ok = row < rows;
+    const int cy = row / Wd, cx = row - cy * Wd;
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+      srow[0][tap] = on ? row + dy * Wd + dx : rows;
+    }
+  }
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
+  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
+  uint32_t dvec = lane < OP_DWORDS ? ops_words[lane] : 0u;
+  for (int o = 0; o < n_ops; ++o) {
+    Fused16Op op;
+    {
+      uint32_t words[OP_DWORDS];
+#pragma unroll
+      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
+      __builtin_memcpy(&op, words, sizeof(Fused16Op));
+    }
+    if (o + 1 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 1) * OP_DWORDS + lane];
+    const int kgt = op.kg0;
+    for (int ct = half; ct < op.ntiles; ct += 2) {
+      f32x4 acc[1];
+      u32x4 bq[WAVE_AHEAD + 1][3];
+      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow, ct, lane, bq);
+      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow, ct, lane, bq);
+      wave_epilogue(acc[0], net, op, rt, ct, lane, rows);
+    }
+    quad_sync(flags, quad, seq, lane);
+  }
+}
+template <bool HEX>
+__global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void netbench4_kernel(PersistArgs q, int iters, unsigned long long* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int slot = wave >> 2, quad = wave & 3;                // a game's four wavefronts sit on the four SIMDs
+  if (threadIdx.x < PERSIST_GAMES * 4)
+    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+  __syncthreads();
+  unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
+  int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
+  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
+  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
+#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
+  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+#undef PHDR
+  if (quad == 0)
+    for (int i = lane * 4; i < q.net_floats; i += 256) *reinterpret_cast<f32x4*>(net + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  int seq = 0;
+  quad_sync(flags, quad, seq, lane);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  const int active = iters >> 16 ? iters >> 16 : PERSIST_GAMES, n_it = iters & 0xffff;
+  if (slot < active)
+    for (int it = 0; it < n_it; ++it) quad_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, quad, flags, seq);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (quad == 0 && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)n_it;
+}
+
 // Diagnostic: the network part of persist_kernel alone -- every game slot of every workgroup runs `iters` passes on an
 // all-zero input (leader + helper exactly as in the search), out[block * PERSIST_GAMES + slot] = shader ticks per pass.
 template <bool HEX>
@@ -1464,9 +1560,11 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
   int seq = 0;
   pair_sync(flags, leader ? 0 : 1, seq, lane);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  for (int it = 0; it < iters; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq);
+  const int active = iters >> 16 ? iters >> 16 : PERSIST_GAMES, n_it = iters & 0xffff;
+  if (slot < active)
+    for (int it = 0; it < n_it; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)iters;
+  if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)n_it;
 }
 
 __global__ void search_status_kernel(SearchParams p, int32_t* out) {
@@ -2518,6 +2616,7 @@ nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out10_host) {  
 // slots each running `iters` passes; ticks_host[blocks * 4].
 nz_status nz_scs_netbench(nz_boardnet* net, int32_t blocks, int32_t iters, uint64_t* ticks_host) {
   if (!net || blocks <= 0 || iters <= 0 || !ticks_host) return NZ_ERR_ARG;
+  const bool quad = getenv("NZ_NETBENCH_QUAD") != nullptr;        // prototype: four wavefronts per game
   nz::WaveNet wn{};
   std::string why;
   if (!nz::boardnet_wave_program(net, &wn, &why)) return sfail(nullptr, NZ_ERR_STATE, "%s", why.c_str());
@@ -2530,7 +2629,13 @@ nz_status nz_scs_netbench(nz_boardnet* net, int32_t blocks, int32_t iters, uint6
   S_HIP(nullptr, hipMalloc((void**)&out, (size_t)blocks * PERSIST_GAMES * 8));
   hipError_t e = wn.hex ? hipFuncSetAttribute((const void*)netbench_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
                         : hipFuncSetAttribute((const void*)netbench_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess) {
+  if (e == hipSuccess && quad && !wn.hex) {
+    e = hipFuncSetAttribute((const void*)netbench4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(netbench4_kernel<false>, dim3(blocks), dim3(PERSIST_GAMES * 4 * 64), lds, nullptr, q, iters, out);
+      e = hipDeviceSynchronize();
+    }
+  } else if (e == hipSuccess) {
     if (wn.hex) hipLaunchKernelGGL(netbench_kernel<true>, dim3(blocks), dim3(PERSIST_THREADS), lds, nullptr, q, iters, out);
     else hipLaunchKernelGGL(netbench_kernel<false>, dim3(blocks), dim3(PERSIST_THREADS), lds, nullptr, q, iters, out);
     e = hipDeviceSynchronize();

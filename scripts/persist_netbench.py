@@ -17,8 +17,10 @@ from nuzero_amd.weights import synthetic_weights, convnet_param_shapes   # noqa:
 cfg = ScsGameConfig(os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
 net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=8, max_batch=1024)
 net.set_weights(synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 8)))
-for blocks in (1, 64, 256):
-    out = np.zeros(blocks * 4, np.uint64)
-    st = lib.nz_scs_netbench(net._h, blocks, 50, ctypes.c_void_p(out.ctypes.data))
-    assert st == 0, st
-    print(f"{blocks} workgroups: ticks per pass min {out.min()} median {int(np.median(out))} max {out.max()}")
+for active in (4, 2, 1):               # game slots of a workgroup that run passes (the others stay idle)
+    for blocks in (1, 256):
+        out = np.zeros(blocks * 4, np.uint64)
+        st = lib.nz_scs_netbench(net._h, blocks, 50 | (active << 16), ctypes.c_void_p(out.ctypes.data))
+        assert st == 0, st
+        out = out.reshape(blocks, 4)[:, :active]
+        print(f"{active} of 4 game slots, {blocks} workgroups: ticks per pass min {out.min()} median {int(np.median(out))} max {out.max()}")
