@@ -722,7 +722,7 @@ struct PersistArgs {
 constexpr int PERSIST_GAMES = 4;                 // games per workgroup
 constexpr int PERSIST_WAVES = 2 * PERSIST_GAMES;  // a leader and a helper wavefront per game
 constexpr int PERSIST_THREADS = PERSIST_WAVES * 64;
-constexpr int PERSIST_FLAG_BYTES = 16;           // per game: the two step numbers of pair_sync, the pass number / exit word
+constexpr int PERSIST_FLAG_BYTES = 32;           // per game: the step numbers of its (up to four) wavefronts, the pass number / exit word
 constexpr int PERSIST_EXIT = 0x7fffffff;
 constexpr int PERSIST_STATE_BYTES = (int)((sizeof(ScsState) + 15) / 16 * 16);
 constexpr int PERSIST_MASK_BYTES = (MASK_WORDS * 4 + 15) / 16 * 16;
@@ -989,8 +989,61 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
   }
 }
 
-// the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
+// ---- FOUR wavefronts per game, one (row tile, column tile) each (persist_kernel4; NZ_SCS_PERSIST_WPG=4) -----------------
+__device__ __forceinline__ void quad_sync(int* flags, int me, int& seq, int lane) {
+  ++seq;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int o = 0; o < 4; ++o)
+    while (__hip_atomic_load(&flags[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 template <bool HEX>
+__device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
+                                             int H, int Wd, int lane, int quad, int* flags, int& seq) {
+  constexpr int ntaps = HEX ? 7 : 9;
+  const int rt = quad & 1, half = quad >> 1;
+  int srow[1][ntaps];
+  {
+    const int row = rt * 16 + (lane & 15);
+    const bool row_ok = row < rows;
+    const int cy = row / Wd, cx = row - cy * Wd;
+#pragma unroll
+    for (int tap = 0; tap < ntaps; ++tap) {
+      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+      srow[0][tap] = on ? row + dy * Wd + dx : rows;
+    }
+  }
+  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
+  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
+  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
+  uint32_t dvec = lane < OP_DWORDS ? ops_words[lane] : 0u;
+  for (int o = 0; o < n_ops; ++o) {
+    Fused16Op op;
+    {
+      uint32_t words[OP_DWORDS];
+#pragma unroll
+      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
+      __builtin_memcpy(&op, words, sizeof(Fused16Op));
+    }
+    if (o + 1 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 1) * OP_DWORDS + lane];
+    const int kgt = op.kg0;
+    for (int ct = half; ct < op.ntiles; ct += 2) {
+      f32x4 acc[1];
+      u32x4 bq[WAVE_AHEAD + 1][3];
+      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow, ct, lane, bq);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow, ct, lane, bq);
+      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow, ct, lane, bq);
+      wave_epilogue(acc[0], net, op, rt, ct, lane, rows);
+    }
+    quad_sync(flags, quad, seq, lane);
+  }
+}
+// the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
+template <bool HEX, int WPG = 2>
 __device__ __forceinline__ void persist_leader(const SearchParams& p, const PersistArgs& q, const ScsRules& R, unsigned char* wb,
                                                int g, const int lane_in, int* flags, int* go) {
   int lane = lane_in;
@@ -1242,7 +1295,8 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
 #ifdef NZ_PERSIST_STAMPS
       wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq, tk + 10);
 #else
-      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
+      if constexpr (WPG == 4) quad_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
+      else wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
 #endif
       PSTAMP(4);                                // network
 
@@ -1418,13 +1472,13 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
       uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)r * PERSIST_RULES_BYTES);
       for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_THREADS) dst[i] = src[i];
     }
-    if (threadIdx.x < PERSIST_GAMES * 4)
-      reinterpret_cast<int*>(smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+    if (threadIdx.x < PERSIST_GAMES * 8)
+      reinterpret_cast<int*>(smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 3) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 7] = 0;
   }
   __syncthreads();
   unsigned char* const wb = smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
   int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
-  int* const go = flags + 2;
+  int* const go = flags + 4;
   const int g = blockIdx.x * PERSIST_GAMES + slot;
   if (leader) {
     if (g < p.n_games) persist_leader<HEX>(p, q, R, wb, g, lane, flags, go);
@@ -1451,67 +1505,67 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   }
 }
 
-// ---- prototype (diagnostic only): FOUR wavefronts per game, one (row tile, column tile) each ------------------------
-__device__ __forceinline__ void quad_sync(int* flags, int me, int& seq, int lane) {
-  ++seq;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (int o = 0; o < 4; ++o)
-    while (__hip_atomic_load(&flags[o], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 template <bool HEX>
-__device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
-                                             int H, int Wd, int lane, int quad, int* flags, int& seq) {
-  constexpr int ntaps = HEX ? 7 : 9;
-  const int rt = quad & 1, half = quad >> 1;
-  int srow[1][ntaps];
-  {
-    const int row = rt * 16 + (lane & 15);
-    const bool row_ok = row < rows;
-    const int cy = row / Wd, cx = row - cy * Wd;
-#pragma unroll
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
-      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
-      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
-      srow[0][tap] = on ? row + dy * Wd + dx : rows;
+__global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void persist_kernel4(SearchParams p, PersistArgs q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // four wavefronts per game, on the four SIMDs; game s is led by wavefront 4 s + s, so that every SIMD hosts one leader
+  const int slot = wave >> 2;
+  const int role = ((wave & 3) - slot) & 3;        // 0: leader, tile (row tile 0, column tiles 0, 2, ..); 1: (1, even); 2: (0, odd); 3: (1, odd)
+  const bool leader = role == 0;
+  const int n_rules = q.rules_per_game ? PERSIST_GAMES : 1;       // descriptions in LDS: one, or one per game slot (its own map)
+  const ScsRules& R = *reinterpret_cast<const ScsRules*>(smem + (size_t)(q.rules_per_game ? slot : 0) * PERSIST_RULES_BYTES);
+  {   // rules -> LDS, once per workgroup, and the games' flag words; the only workgroup barrier of the kernel
+    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
+    for (int r = 0; r < n_rules; ++r) {
+      const int gr = blockIdx.x * PERSIST_GAMES + r;
+      if (gr >= p.n_games) break;
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(&rules_of(p, gr));
+      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)r * PERSIST_RULES_BYTES);
+      for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_GAMES * 4 * 64) dst[i] = src[i];
     }
+    if (threadIdx.x < PERSIST_GAMES * 8)
+      reinterpret_cast<int*>(smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 3) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 7] = 0;
   }
+  __syncthreads();
+  unsigned char* const wb = smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
+  int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
+  int* const go = flags + 4;
+  const int g = blockIdx.x * PERSIST_GAMES + slot;
+  if (leader) {
+    if (g < p.n_games) persist_leader<HEX, 4>(p, q, R, wb, g, lane, flags, go);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+  // helper: one tile of every layer of every network pass of its game, asleep in between
+  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
   typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
-  constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
-  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
-  uint32_t dvec = lane < OP_DWORDS ? ops_words[lane] : 0u;
-  for (int o = 0; o < n_ops; ++o) {
-    Fused16Op op;
-    {
-      uint32_t words[OP_DWORDS];
-#pragma unroll
-      for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(dvec, i);
-      __builtin_memcpy(&op, words, sizeof(Fused16Op));
-    }
-    if (o + 1 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 1) * OP_DWORDS + lane];
-    const int kgt = op.kg0;
-    for (int ct = half; ct < op.ntiles; ct += 2) {
-      f32x4 acc[1];
-      u32x4 bq[WAVE_AHEAD + 1][3];
-      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow, ct, lane, bq);
-      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow, ct, lane, bq);
-      wave_epilogue(acc[0], net, op, rt, ct, lane, rows);
-    }
-    quad_sync(flags, quad, seq, lane);
+  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
+  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
+#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
+  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+#undef PHDR
+  int seq = 0, pass = 0;
+  for (;;) {
+    int gv;
+    while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(8);
+    if (gv == PERSIST_EXIT) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    pass = gv;
+    quad_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, role, flags, seq);
   }
 }
+
 template <bool HEX>
 __global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void netbench4_kernel(PersistArgs q, int iters, unsigned long long* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int slot = wave >> 2, quad = wave & 3;                // a game's four wavefronts sit on the four SIMDs
-  if (threadIdx.x < PERSIST_GAMES * 4)
-    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+  if (threadIdx.x < PERSIST_GAMES * 8)
+    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 3) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 7] = 0;
   __syncthreads();
   unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
   int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
@@ -1543,8 +1597,8 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const bool leader = wave < PERSIST_GAMES;
   const int slot = leader ? wave : ((wave - PERSIST_GAMES + 3) & (PERSIST_GAMES - 1));
-  if (threadIdx.x < PERSIST_GAMES * 4)
-    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 2) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 3] = 0;
+  if (threadIdx.x < PERSIST_GAMES * 8)
+    reinterpret_cast<int*>(smem + PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 3) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 7] = 0;
   __syncthreads();
   unsigned char* const wb = smem + PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
   int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
@@ -2118,6 +2172,7 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
   bool persist = false;
   size_t persist_lds = 0;
   h->persist_used = 0;
+  static const int persist_wpg = getenv("NZ_SCS_PERSIST_WPG") ? atoi(getenv("NZ_SCS_PERSIST_WPG")) : 2;   // wavefronts per game: 2 or 4
   {
     static const int env_mode = getenv("NZ_SCS_PERSIST") ? atoi(getenv("NZ_SCS_PERSIST")) : -1;       // A/B experiments
     const int mode = h->persist_mode >= 0 ? h->persist_mode : env_mode;
@@ -2135,9 +2190,12 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
       persist_lds = (size_t)(q.rules_per_game ? PERSIST_GAMES : 1) * PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
       if (persist_lds > 160 * 1024) h->persist_why = "four games' blocks do not fit in LDS";
       else {
-        const hipError_t e = wn.hex
+        hipError_t e = wn.hex
             ? hipFuncSetAttribute((const void*)persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds)
             : hipFuncSetAttribute((const void*)persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
+        if (e == hipSuccess && persist_wpg == 4)
+          e = wn.hex ? hipFuncSetAttribute((const void*)persist_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds)
+                     : hipFuncSetAttribute((const void*)persist_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
         if (e != hipSuccess) { (void)hipGetLastError(); h->persist_why = "hipFuncSetAttribute failed"; }
         else { persist = true; h->persist_why.clear(); }
       }
@@ -2289,10 +2347,14 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
         if (!h->ev_p0) { S_HIP(h, hipEventCreate(&h->ev_p0)); S_HIP(h, hipEventCreate(&h->ev_p1)); }
         S_HIP(h, hipEventRecord(h->ev_p0, s));
       }
-      if (h->persist_used == 2)
-        hipLaunchKernelGGL(persist_kernel<true>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
+      const dim3 pgrid((G + PERSIST_GAMES - 1) / PERSIST_GAMES);
+      if (persist_wpg == 4) {
+        if (h->persist_used == 2) hipLaunchKernelGGL(persist_kernel4<true>, pgrid, dim3(PERSIST_GAMES * 4 * 64), persist_lds, s, h->p, h->pq);
+        else hipLaunchKernelGGL(persist_kernel4<false>, pgrid, dim3(PERSIST_GAMES * 4 * 64), persist_lds, s, h->p, h->pq);
+      } else if (h->persist_used == 2)
+        hipLaunchKernelGGL(persist_kernel<true>, pgrid, dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       else
-        hipLaunchKernelGGL(persist_kernel<false>, dim3((G + PERSIST_GAMES - 1) / PERSIST_GAMES), dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
+        hipLaunchKernelGGL(persist_kernel<false>, pgrid, dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       S_HIP(h, hipGetLastError());
       ++h->waves;
       static const bool move_times = getenv("NZ_SCS_MOVE_TIMES") != nullptr;     // experiment: the duration of every move's launch
