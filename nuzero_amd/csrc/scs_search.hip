@@ -138,18 +138,21 @@ __device__ __forceinline__ double child_score(const SearchParams& p, const SNode
 // structure matter.  Wave-uniform: lane i holds the i-th non-zero entry (idx ascending, val), every lane walks the
 // block program of SearchParams (built on the host) with the entries broadcast by v_readlane -- no memory accesses.
 // Entry j lives in lane j & 63 of register j >> 6 (up to MAXC_CHUNKS registers per lane).
-__device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, const int (&idx)[MAXC_CHUNKS],
-                                                        const float (&val)[MAXC_CHUNKS], int k) {
+template <int CH = MAXC_CHUNKS>
+__device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, const int (&idx)[CH],
+                                                        const float (&val)[CH], int k) {
   float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f, st4 = 0.f, st5 = 0.f, st6 = 0.f, st7 = 0.f;   // block-sum stack
   int sp = 0, i = 0, lo = 0;
   auto entry_idx = [&](int j) {
     const int c = __builtin_amdgcn_readfirstlane(j >> 6), l = __builtin_amdgcn_readfirstlane(j & 63);
-    const int r = c == 0 ? idx[0] : c == 1 ? idx[1] : c == 2 ? idx[2] : idx[3];
+    int r = idx[0];
+    if constexpr (CH > 1) r = c == 0 ? idx[0] : c == 1 ? idx[1] : c == 2 ? idx[2 % CH] : idx[3 % CH];
     return __builtin_amdgcn_readlane(r, l);
   };
   auto entry_val = [&](int j) {
     const int c = __builtin_amdgcn_readfirstlane(j >> 6), l = __builtin_amdgcn_readfirstlane(j & 63);
-    const float r = c == 0 ? val[0] : c == 1 ? val[1] : c == 2 ? val[2] : val[3];
+    float r = val[0];
+    if constexpr (CH > 1) r = c == 0 ? val[0] : c == 1 ? val[1] : c == 2 ? val[2 % CH] : val[3 % CH];
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), l));
   };
   for (int b = 0; b < p.pw_blocks; ++b) {
@@ -904,7 +907,12 @@ __device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane
   ++seq;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(&flags[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(1);
+#ifndef NZ_PERSIST_SYNC_SLEEP
+#define NZ_PERSIST_SYNC_SLEEP 0
+#endif
+  while (__hip_atomic_load(&flags[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) {
+    if (NZ_PERSIST_SYNC_SLEEP > 0) __builtin_amdgcn_s_sleep(NZ_PERSIST_SYNC_SLEEP);
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
@@ -1043,7 +1051,7 @@ __device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ 
   }
 }
 // the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
-template <bool HEX, int WPG = 2>
+template <bool HEX, int WPG = 2, int CH = MAXC_CHUNKS>
 __device__ __forceinline__ void persist_leader(const SearchParams& p, const PersistArgs& q, const ScsRules& R, unsigned char* wb,
                                                int g, const int lane_in, int* flags, int* go) {
   int lane = lane_in;
@@ -1374,10 +1382,10 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         ++rec_n;
       }
       // expansion (Explorer.py:162-181): child j = the j-th legal action, prior = masked prob / their float32 np.sum
-      int my_idx[MAXC_CHUNKS];
-      float my_val[MAXC_CHUNKS];
+      int my_idx[CH];                         // (CH = 1: this game has at most 64 legal actions in a position)
+      float my_val[CH];
 #pragma unroll
-      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+      for (int c = 0; c < CH; ++c) {
         const int j = c * 64 + lane;
         my_idx[c] = j < k ? sidx[j] : 0x7fffffff;
         float pr = 0.0f;
@@ -1387,14 +1395,14 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         }
         my_val[c] = pr;
       }
-      float total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
+      float total = np_sum_sparse_f32_wave<CH>(p, my_idx, my_val, k);
       if (total == 0.0f) {
 #pragma unroll
-        for (int c = 0; c < MAXC_CHUNKS; ++c) my_val[c] = my_val[c] + 1.0f;
-        total = np_sum_sparse_f32_wave(p, my_idx, my_val, k);
+        for (int c = 0; c < CH; ++c) my_val[c] = my_val[c] + 1.0f;
+        total = np_sum_sparse_f32_wave<CH>(p, my_idx, my_val, k);
       }
 #pragma unroll
-      for (int c = 0; c < MAXC_CHUNKS; ++c) {
+      for (int c = 0; c < CH; ++c) {
         const int j = c * 64 + lane;
         if (j < k) {
           SNode n;
@@ -1452,7 +1460,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   }
 }
 
-template <bool HEX>
+template <bool HEX, int CH = MAXC_CHUNKS>
 __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p, PersistArgs q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
@@ -1481,7 +1489,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   int* const go = flags + 4;
   const int g = blockIdx.x * PERSIST_GAMES + slot;
   if (leader) {
-    if (g < p.n_games) persist_leader<HEX>(p, q, R, wb, g, lane, flags, go);
+    if (g < p.n_games) persist_leader<HEX, 2, CH>(p, q, R, wb, g, lane, flags, go);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -1497,7 +1505,10 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   int seq = 0, pass = 0;
   for (;;) {
     int gv;
-    while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(8);
+#ifndef NZ_PERSIST_GO_SLEEP
+#define NZ_PERSIST_GO_SLEEP 2
+#endif
+    while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(NZ_PERSIST_GO_SLEEP);
     if (gv == PERSIST_EXIT) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     pass = gv;
@@ -1505,7 +1516,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   }
 }
 
-template <bool HEX>
+template <bool HEX, int CH = MAXC_CHUNKS>
 __global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void persist_kernel4(SearchParams p, PersistArgs q) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = lane_id();
@@ -1534,7 +1545,7 @@ __global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void persist_kernel4(Search
   int* const go = flags + 4;
   const int g = blockIdx.x * PERSIST_GAMES + slot;
   if (leader) {
-    if (g < p.n_games) persist_leader<HEX, 4>(p, q, R, wb, g, lane, flags, go);
+    if (g < p.n_games) persist_leader<HEX, 4, CH>(p, q, R, wb, g, lane, flags, go);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -1758,6 +1769,18 @@ __global__ __launch_bounds__(64) void compact_kernel(SearchParams p) {
   }
 }
 
+// the persistent kernel for a network (square / hexagonal taps), wavefronts per game and the game's children bound
+// (at most 64 legal actions per position: the expansion handles one chunk of children instead of four)
+typedef void (*persist_fn_t)(SearchParams, PersistArgs);
+persist_fn_t persist_pick(bool hex, int wpg, bool one_chunk) {
+  if (wpg == 4) {
+    if (hex) return one_chunk ? persist_kernel4<true, 1> : persist_kernel4<true, MAXC_CHUNKS>;
+    return one_chunk ? persist_kernel4<false, 1> : persist_kernel4<false, MAXC_CHUNKS>;
+  }
+  if (hex) return one_chunk ? persist_kernel<true, 1> : persist_kernel<true, MAXC_CHUNKS>;
+  return one_chunk ? persist_kernel<false, 1> : persist_kernel<false, MAXC_CHUNKS>;
+}
+
 }  // namespace
 
 struct nz_scs_search {
@@ -1787,6 +1810,7 @@ struct nz_scs_search {
   // persistent route (persist_kernel): -1 follow the default (on where the network has a per-wavefront form), 0 off, 1 on
   int persist_mode = -1;
   int persist_used = 0;                       // the last play ran on it
+  void (*persist_fn)(SearchParams, PersistArgs) = nullptr;     // the kernel variant of the last play
   bool persist_profile = false;               // HIP events around every persist_kernel launch (nz_scs_search_persist_profile)
   hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr;
   double persist_ms = 0.0;
@@ -2190,12 +2214,8 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
       persist_lds = (size_t)(q.rules_per_game ? PERSIST_GAMES : 1) * PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
       if (persist_lds > 160 * 1024) h->persist_why = "four games' blocks do not fit in LDS";
       else {
-        hipError_t e = wn.hex
-            ? hipFuncSetAttribute((const void*)persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds)
-            : hipFuncSetAttribute((const void*)persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
-        if (e == hipSuccess && persist_wpg == 4)
-          e = wn.hex ? hipFuncSetAttribute((const void*)persist_kernel4<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds)
-                     : hipFuncSetAttribute((const void*)persist_kernel4<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
+        h->persist_fn = persist_pick(wn.hex != 0, persist_wpg, h->p.maxc <= 64);
+        const hipError_t e = hipFuncSetAttribute((const void*)h->persist_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
         if (e != hipSuccess) { (void)hipGetLastError(); h->persist_why = "hipFuncSetAttribute failed"; }
         else { persist = true; h->persist_why.clear(); }
       }
@@ -2348,13 +2368,7 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
         S_HIP(h, hipEventRecord(h->ev_p0, s));
       }
       const dim3 pgrid((G + PERSIST_GAMES - 1) / PERSIST_GAMES);
-      if (persist_wpg == 4) {
-        if (h->persist_used == 2) hipLaunchKernelGGL(persist_kernel4<true>, pgrid, dim3(PERSIST_GAMES * 4 * 64), persist_lds, s, h->p, h->pq);
-        else hipLaunchKernelGGL(persist_kernel4<false>, pgrid, dim3(PERSIST_GAMES * 4 * 64), persist_lds, s, h->p, h->pq);
-      } else if (h->persist_used == 2)
-        hipLaunchKernelGGL(persist_kernel<true>, pgrid, dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
-      else
-        hipLaunchKernelGGL(persist_kernel<false>, pgrid, dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
+      hipLaunchKernelGGL(h->persist_fn, pgrid, dim3((persist_wpg == 4 ? 4 : 2) * PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
       S_HIP(h, hipGetLastError());
       ++h->waves;
       static const bool move_times = getenv("NZ_SCS_MOVE_TIMES") != nullptr;     // experiment: the duration of every move's launch
