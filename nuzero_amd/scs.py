@@ -572,8 +572,9 @@ class ScsGameRecord:
     """A finished SCS game as ReplayBuffer.save_game and the trainer read it
     (Training/ReplayBuffer.py:31-33, SCS_Game.py:1517-1528)."""
 
-    def __init__(self, states, child_actions, child_visits, n_children, length, terminal_value, num_actions):
+    def __init__(self, states, child_actions, child_visits, n_children, length, terminal_value, num_actions, actions=None):
         self.length, self.terminal_value = int(length), int(terminal_value)
+        self.action_history = [int(a) for a in actions[:self.length]] if actions is not None else None
         self.state_history = [torch.from_numpy(np.ascontiguousarray(states[m:m + 1])) for m in range(self.length)]
         self.child_policy = []
         for m in range(self.length):
@@ -607,4 +608,4 @@ def scs_game_records(selfplay, result):
         batch.step(np.where(m < lengths, result["actions"][:, m], -1).astype(np.int32))
     batch.close()
     return [ScsGameRecord(states[g], result["child_action"][g], result["child_visit"][g], result["n_children"][g],
-                          lengths[g], result["outcomes"][g], cfg.num_actions) for g in range(G)]
+                          lengths[g], result["outcomes"][g], cfg.num_actions, result["actions"][g]) for g in range(G)]

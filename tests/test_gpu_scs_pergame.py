@@ -137,3 +137,57 @@ def test_1024_different_maps_in_one_engine_both_routes_and_refill():
     rr = small.play_round(net, seeds[:300])
     _same_games(rr, rp, [(g, g) for g in range(300)], "refill on own maps")
     small.close(); net.close()
+
+
+def test_gamer_gives_every_game_its_own_map_and_fills_the_buffers():
+    """Gamer(..., SCS_Game, [randomized config], ...): game i of a round = np.random.seed(base_seed + i); SCS_Game(config);
+    play.  A round of more games than trees, with the inference cache on (the reference's default presets); the host
+    records (states regenerated on each game's own map) equal the oracle's images along the recorded actions, and the
+    device replay buffer holds the same positions."""
+    import torch
+    from nuzero_amd.gamer import Gamer
+    from nuzero_amd.network import Network_Manager
+    from nuzero_amd.replay_buffer import ReplayBuffer
+    from nuzero_amd.replay_device import DeviceReplayBuffer
+    from nuzero_amd.weights import synthetic_weights, convnet_param_shapes
+    from oracle.scs import ScsConfig, ScsGame
+    from test_gpu_scs_configs import a1_search
+
+    class SCS_Game:
+        pass
+
+    shapes = convnet_param_shapes(86, 21, 3, 32, 2)
+    model = {k: torch.from_numpy(v) for k, v in synthetic_weights(5, shapes, 2.0).items()}
+    nm = Network_Manager(model)
+    host = ReplayBuffer(100, 16)
+    N, base = 10, 7700
+    g = Gamer(host, nm, SCS_Game, [PATH], 3, a1_search(16), 1, "keyless", size_estimate=4096, num_games=N,
+              concurrent_games=4, base_seed=base)
+    assert g.scs_config.per_game
+    records, stats = g.play_games()
+    assert len(records) == N and len(stats) == N and g.engine.persistent()
+    maps = g.engine.game_maps[0]
+    assert len({m.tobytes() for m in maps}) == N
+    for i, rec in enumerate(records):
+        og = ScsGame(ScsConfig(PATH, map_seed=np.random.RandomState(base + i)))
+        assert np.array_equal(np.array(og.cfg.terrain, np.float32).reshape(-1, 3), maps[i])
+        for m in range(rec.length):
+            assert np.array_equal(rec.get_state_from_history(m).numpy(), og.state_image()), (i, m)
+            pol = np.asarray(rec.make_target(m)[1])
+            legal = og.possible_actions().reshape(-1) != 0
+            assert abs(pol.sum() - 1.0) < 1e-9 and not pol[~legal].any()
+            assert legal[rec.action_history[m]]
+            og.step_index(rec.action_history[m])
+        assert og.terminal and og.terminal_value == rec.terminal_value
+    # the same round into a device buffer: same positions
+    dev = DeviceReplayBuffer(100, 16, (86, 5, 5), 525, max_game_length=g.engine.MAX_MOVES)
+    g2 = Gamer(dev, nm, SCS_Game, [PATH], 3, a1_search(16), 1, "keyless", size_estimate=4096, num_games=N,
+               concurrent_games=4, base_seed=base, records=False)
+    _, stats2 = g2.play_games()
+    assert stats2 == stats
+    assert dev.len() == host.len() == sum(rec.length for rec in records)
+    a, b = dev.get_buffer(), host.get_buffer()
+    for x, y in zip(a, b):
+        assert torch.equal(x[0], y[0]) and x[1][0] == y[1][0] and x[2] == y[2]
+        assert x[1][1] == np.asarray(y[1][1], np.float32).tolist()       # (the device buffer keeps policies as float32)
+    dev.close(); g.engine.close(); g2.engine.close()
