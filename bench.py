@@ -42,7 +42,7 @@ Extra keys (N = 1)
   scs_config4_round4  scs_config4 with four games per concurrent tree in one round (nz_scs_search_play_round: a tree
                     whose game has ended starts the round's next game)
   scs_config5       BASELINE.json configs[4] on one GPU, bounded: SCS 10x10, RecurrentNet(256 x 2, recall) x 16 iterations,
-                    400 sims/move, 64 games x their first 2 decisions; expansions/s and the network's rate
+                    400 sims/move, 256 games x their first decision; expansions/s and the network's rate
   ttt_config3_share BASELINE.json configs[2]'s share of one GPU: 1024 concurrent Tic-Tac-Toe games, 400 sims/move
   cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
                     Explorer/Gamer path) on this box's host cores, one process per core, on a bounded sample
@@ -220,11 +220,12 @@ def scs_config4(device, games_per_tree=1):
     return out
 
 
-def scs_config5(device, games=64, moves=2):
+def scs_config5(device, games=256, moves=1):
     """BASELINE.json configs[4] on one GPU, bounded: SCS 10x10 map, RecurrentNet(86 -> 21, 256 filters, 2 blocks, recall,
     relu value head; Run.py:148) with 16 recurrent iterations, 400 simulations per move -- `games` games, the first
     `moves` decisions of each (a whole game is ~120 decisions x 400 evaluations x 9 GFLOP).  Wave-by-wave route: the
-    per-layer board-net kernels (a 256-wide net on 100 cells has no one-launch form)."""
+    per-layer board-net kernels (a 256-wide net on 100 cells has no one-launch form); with 256 concurrent games a
+    wave's leaves fill the 256-position tiles of conv_wide_kernel (split-bf16 MFMA)."""
     import torch
     from nuzero_amd.boardnet import BoardNet
     from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
