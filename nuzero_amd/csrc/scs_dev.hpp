@@ -505,29 +505,48 @@ __device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, in
       s.tile[u] = (int8_t)t;
       game.place(u, t);
     }
-  } else if (lane == 0) {
+  } else {
+    // lane 0 applies the action; the two scans a movement ends with -- "can the unit still move anywhere" (six directions,
+    // check_mobility :1096-1111) and "is an enemy adjacent" (six neighbours x stack, end_movement :927-940) -- are one
+    // lane per direction / per (neighbour, stack entry) and a ballot instead of loops on one lane
+    int ended = -1;                                   // the unit whose movement ends with this action (wave-uniform)
     if (plane < r.movement_limit) {
       const int idx = plane - r.placement_limit, lvl = idx % S, dir = idx / S;
       const int u = s.stack[t][lvl], dest = r.neighbour[t][dir];
-      s.mov[u] = (int8_t)(s.mov[u] - r.cost[dest]);
-      s.tile[u] = (int8_t)dest;
-      game.place(u, dest);
-      game.remove(u, t);
-      bool any = false;
-      for (int d = 0; d < 6; ++d) any |= game.can_move(u, d, false);
-      if (!any) game.end_movement(u);
+      if (lane == 0) {
+        s.mov[u] = (int8_t)(s.mov[u] - r.cost[dest]);
+        s.tile[u] = (int8_t)dest;
+        game.place(u, dest);
+        game.remove(u, t);
+      }
+      scs_sync<ONEWAVE>();
+      const bool can = lane < 6 && game.can_move(u, lane, false);
+      if (__ballot(can) == 0ull) ended = u;
     } else if (plane < r.target_limit) {
-      s.target = (int8_t)t;
+      if (lane == 0) s.target = (int8_t)t;
     } else if (plane < r.attackers_limit) {
-      s.attackers[s.n_attackers++] = s.stack[t][plane - r.target_limit];
+      if (lane == 0) s.attackers[s.n_attackers++] = s.stack[t][plane - r.target_limit];
     } else if (plane < r.confirm_limit) {
-      game.resolve_combat();
-      s.target = -1;
-      s.n_attackers = 0;
+      if (lane == 0) {
+        game.resolve_combat();
+        s.target = -1;
+        s.n_attackers = 0;
+      }
     } else if (plane < r.no_move_limit) {
-      game.end_movement(s.stack[t][plane - r.confirm_limit]);
+      ended = s.stack[t][plane - r.confirm_limit];
     } else {
-      game.end_fighting(s.stack[t][plane - r.no_move_limit]);
+      if (lane == 0) game.end_fighting(s.stack[t][plane - r.no_move_limit]);
+    }
+    if (ended >= 0) {                                 // end_movement(ended)
+      const int tile = s.tile[ended], enemy = r.u_player[ended] ^ 1;
+      bool adj = false;
+      if (lane < 6 * SCS_MAX_STACK) {
+        const int d = lane / SCS_MAX_STACK, i = lane - d * SCS_MAX_STACK;
+        const int n = r.neighbour[tile][d];
+        adj = n >= 0 && i < s.stack_n[n] && r.u_player[s.stack[n][i]] == enemy;
+      }
+      const bool any_adj = __ballot(adj) != 0ull;
+      if (lane == 0) s.status[ended] = any_adj ? SCS_MOVED : SCS_ATTACKED;
     }
   }
   if (lane == 0) ++s.length;
