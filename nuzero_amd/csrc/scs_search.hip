@@ -997,7 +997,8 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
   }
 }
 
-// ---- FOUR wavefronts per game, one (row tile, column tile) each (persist_kernel4; NZ_SCS_PERSIST_WPG=4) -----------------
+// ---- diagnostic: FOUR wavefronts per game, one (row tile, column tile) each (netbench4_kernel; as a search kernel it
+// lost to the pair: at 128 registers the leader's tree code spills) -----------------------------------------------------
 __device__ __forceinline__ void quad_sync(int* flags, int me, int& seq, int lane) {
   ++seq;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1050,14 +1051,68 @@ __device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ 
     quad_sync(flags, quad, seq, lane);
   }
 }
+// The ascending list of a position's legal actions (Explorer.py:163-165): the mask in LDS, then lane w enumerates mask
+// word w (and word 64 + w) behind a prefix sum of the words' bit counts.  Returns their number.
+__device__ __forceinline__ int legal_list_wave(const ScsRules& R, const ScsState& sc, uint32_t* smask, int* sidx, int lane) {
+  scs_legal_mask_wave<MASK_WORDS, false>(R, sc, smask, lane);
+  int k = 0;
+#pragma unroll
+  for (int w = 0; w < (MASK_WORDS + 63) / 64; ++w) {
+    uint32_t bits = w * 64 + lane < MASK_WORDS ? smask[w * 64 + lane] : 0u;
+    int inc = __popc(bits);
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    int off = k + inc - __popc(bits);
+    while (bits) {
+      const int b = __ffs(bits) - 1;
+      bits &= bits - 1;
+      if (off < MAXC_LIMIT) sidx[off] = (w * 64 + lane) * 32 + b;
+      ++off;
+    }
+    k += __shfl(inc, 63, 64);
+  }
+  return k;
+}
+// This wavefront's half (`half` = 0 leader, 1 helper) of turning the staged float32 planes into the input pieces (every
+// row of the input region, its row of zeros included) ...
+__device__ __forceinline__ void split_planes_half(float* __restrict__ net, const PersistArgs& q, int hw, int in_off, int in_cs,
+                                                  int in_ps, int lane, int half) {
+  const float* const stage = net + q.stage_off;
+  const int chunks = q.inp >> 3;
+  for (int i = lane + 64 * half; i < (hw + 1) * chunks; i += 128) {
+    const int r = i / chunks, c8 = i - r * chunks;
+    u32x4 q0 = u32x4{0u, 0u, 0u, 0u}, q1 = q0, q2 = q0;
+    if (r < hw) {
+      f32x4 lo4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8);
+      f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c8 * 8 + j >= q.in_channels) lo4[j] = 0.f;
+        if (c8 * 8 + 4 + j >= q.in_channels) hi4[j] = 0.f;
+      }
+      wide_split8(lo4, hi4, q0, q1, q2);
+    }
+    float* d = net + in_off + r * in_cs + ((c8 ^ ((r >> 2) & 3)) << 2);
+    *reinterpret_cast<u32x4*>(d) = q0;
+    *reinterpret_cast<u32x4*>(d + in_ps) = q1;
+    *reinterpret_cast<u32x4*>(d + 2 * in_ps) = q2;
+  }
+}
+// ... and of zeroing the staging space again (it lies over the trunk buffers: their rows of zeros, channels no layer writes)
+__device__ __forceinline__ void zero_stage_half(float* __restrict__ net, const PersistArgs& q, int lane, int half) {
+  float* const stage = net + q.stage_off;
+  for (int i = (lane + 64 * half) * 4; i < q.stage_floats; i += 512) *reinterpret_cast<f32x4*>(stage + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // the search of one game's move: the leader wavefront's body (returns when the move's simulations are used up)
-template <bool HEX, int WPG = 2, int CH = MAXC_CHUNKS>
+template <bool HEX, int CH = MAXC_CHUNKS>
 __device__ __forceinline__ void persist_leader(const SearchParams& p, const PersistArgs& q, const ScsRules& R, unsigned char* wb,
                                                int g, const int lane_in, int* flags, int* go) {
   int lane = lane_in;
   ScsState& real_l = *reinterpret_cast<ScsState*>(wb);
   ScsState& sc = *reinterpret_cast<ScsState*>(wb + PERSIST_STATE_BYTES);
-  uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
   int* const sidx = reinterpret_cast<int*>(wb + 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES);
   float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
   int seq = 0, pass = 0;
@@ -1178,33 +1233,12 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       v = (double)sc.terminal_value;
     } else {
       if (lane == 0) nodes[node].to_play = (int8_t)to_play;
-      // legal actions: mask, then the ascending list (Explorer.py:163-165)
-      scs_legal_mask_wave<MASK_WORDS, false>(R, sc, smask, lane);
-      int k = 0;
-#pragma unroll
-      for (int w = 0; w < (MASK_WORDS + 63) / 64; ++w) {
-        uint32_t bits = w * 64 + lane < MASK_WORDS ? smask[w * 64 + lane] : 0u;
-        int inc = __popc(bits);
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o = __shfl_up(inc, d, 64);
-          if (lane >= d) inc += o;
-        }
-        int off = k + inc - __popc(bits);
-        while (bits) {
-          const int b = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (off < MAXC_LIMIT) sidx[off] = (w * 64 + lane) * 32 + b;
-          ++off;
-        }
-        k += __shfl(inc, 63, 64);
-      }
-      const bool overflow = k > p.maxc;
-      if (overflow || base + k > p.half_cap) {
-        if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
-        failed = true;
-        break;
-      }
-      PSTAMP(2);                                // legal mask + list
+      // The helper wavefront starts NOW on the leaf's legal mask and list (it is needed only at the expansion), while this
+      // one looks the leaf up in the cache and stages its planes; they meet before the planes are split.
+      ++pass;
+      if (lane == 0) flags[7] = base;             // (what the helper's own overflow check needs)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_store(go, pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       float* const pol = net + pol_off;
       // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
       const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
@@ -1266,45 +1300,36 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         scs_sync<false>();
       }
       if (!hit) {
-      // the leaf's planes (generate_network_input, SCS_Game.py:1507): float32 rows over the trunk buffers' space, split
-      // into the input pieces, then that space is zeros again (the buffers' rows of zeros, channels no layer writes)
-      float* const stage = net + q.stage_off;
-      scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
-      scs_sync<false>();
-      if (rec >= 0) image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
+        // the leaf's planes (generate_network_input, SCS_Game.py:1507) as float32 rows over the trunk buffers' space
+        float* const stage = net + q.stage_off;
+        scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
+        scs_sync<false>();
+        if (rec >= 0) image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
+      }
+      PSTAMP(2);                                // cache lookup + planes (the helper: legal mask + list)
+      if (lane == 0) flags[5] = hit ? 0 : 1;      // what the helper does after the meeting: nothing more / its half of the pass
+      pair_sync(flags, 0, seq, lane);
+      const int k = flags[6];                     // the helper's count of legal actions (the list is in sidx)
       {
-        const int chunks = q.inp >> 3;
-        for (int i = lane; i < (hw + 1) * chunks; i += 64) {
-          const int r = i / chunks, c8 = i - r * chunks;
-          u32x4 q0 = u32x4{0u, 0u, 0u, 0u}, q1 = q0, q2 = q0;
-          if (r < hw) {
-            f32x4 lo4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8);
-            f32x4 hi4 = *reinterpret_cast<const f32x4*>(stage + r * q.inp + c8 * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              if (c8 * 8 + j >= q.in_channels) lo4[j] = 0.f;
-              if (c8 * 8 + 4 + j >= q.in_channels) hi4[j] = 0.f;
-            }
-            wide_split8(lo4, hi4, q0, q1, q2);
-          }
-          float* d = net + in_off + r * in_cs + ((c8 ^ ((r >> 2) & 3)) << 2);
-          *reinterpret_cast<u32x4*>(d) = q0;
-          *reinterpret_cast<u32x4*>(d + in_ps) = q1;
-          *reinterpret_cast<u32x4*>(d + 2 * in_ps) = q2;
+        const bool overflow = k > p.maxc;
+        if (overflow || base + k > p.half_cap) {  // (the helper makes the same check and stops here too)
+          if (lane == 0) atomicOr(p.error_flag, overflow ? 16 : 1);
+          failed = true;
+          break;
         }
       }
+      if (!hit) {
+      split_planes_half(net, q, hw, in_off, in_cs, in_ps, lane, 0);
       scs_sync<false>();
-      for (int i = lane * 4; i < q.stage_floats; i += 256) *reinterpret_cast<f32x4*>(stage + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+      pair_sync(flags, 0, seq, lane);             // (both halves of the pieces are made: the staging space can go)
+      zero_stage_half(net, q, lane, 0);
       scs_sync<false>();
-      PSTAMP(3);                                // planes, split, staging cleared
-      ++pass;                                   // the helper wavefront starts on its half of the layers
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) __hip_atomic_store(go, pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      pair_sync(flags, 0, seq, lane);
+      PSTAMP(3);                                // split, staging cleared (halves)
 #ifdef NZ_PERSIST_STAMPS
       wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq, tk + 10);
 #else
-      if constexpr (WPG == 4) quad_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
-      else wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
+      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
 #endif
       PSTAMP(4);                                // network
 
@@ -1489,7 +1514,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   int* const go = flags + 4;
   const int g = blockIdx.x * PERSIST_GAMES + slot;
   if (leader) {
-    if (g < p.n_games) persist_leader<HEX, 2, CH>(p, q, R, wb, g, lane, flags, go);
+    if (g < p.n_games) persist_leader<HEX, CH>(p, q, R, wb, g, lane, flags, go);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return;
@@ -1501,7 +1526,11 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
 #define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs), in_ps = PHDR(in_ps);
 #undef PHDR
+  const ScsState& sc = *reinterpret_cast<const ScsState*>(wb + PERSIST_STATE_BYTES);
+  uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
+  int* const sidx = reinterpret_cast<int*>(wb + 2 * PERSIST_STATE_BYTES + PERSIST_MASK_BYTES);
   int seq = 0, pass = 0;
   for (;;) {
     int gv;
@@ -1512,60 +1541,20 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
     if (gv == PERSIST_EXIT) break;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     pass = gv;
+    // a leaf that needs an evaluation: its legal mask and list (the leader meanwhile looks it up in the cache and stages
+    // its planes), then -- unless the cache had it -- half of the split into pieces and half of every layer
+    const int k = legal_list_wave(R, sc, smask, sidx, lane);
+    if (lane == 0) flags[6] = k;
+    pair_sync(flags, 1, seq, lane);
+    const int job = flags[5], base = flags[7];
+    if (job == 0 || k > p.maxc || base + k > p.half_cap) continue;     // (a hit, or the leader is raising the overflow flag)
+    split_planes_half(net, q, hw, in_off, in_cs, in_ps, lane, 1);
+    scs_sync<false>();
+    pair_sync(flags, 1, seq, lane);
+    zero_stage_half(net, q, lane, 1);
+    scs_sync<false>();
+    pair_sync(flags, 1, seq, lane);
     wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 1, flags, seq);
-  }
-}
-
-template <bool HEX, int CH = MAXC_CHUNKS>
-__global__ __launch_bounds__(PERSIST_GAMES * 4 * 64) void persist_kernel4(SearchParams p, PersistArgs q) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = lane_id();
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // four wavefronts per game, on the four SIMDs; game s is led by wavefront 4 s + s, so that every SIMD hosts one leader
-  const int slot = wave >> 2;
-  const int role = ((wave & 3) - slot) & 3;        // 0: leader, tile (row tile 0, column tiles 0, 2, ..); 1: (1, even); 2: (0, odd); 3: (1, odd)
-  const bool leader = role == 0;
-  const int n_rules = q.rules_per_game ? PERSIST_GAMES : 1;       // descriptions in LDS: one, or one per game slot (its own map)
-  const ScsRules& R = *reinterpret_cast<const ScsRules*>(smem + (size_t)(q.rules_per_game ? slot : 0) * PERSIST_RULES_BYTES);
-  {   // rules -> LDS, once per workgroup, and the games' flag words; the only workgroup barrier of the kernel
-    static_assert(sizeof(ScsRules) % 4 == 0 && sizeof(ScsState) % 4 == 0, "copied as dwords");
-    for (int r = 0; r < n_rules; ++r) {
-      const int gr = blockIdx.x * PERSIST_GAMES + r;
-      if (gr >= p.n_games) break;
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(&rules_of(p, gr));
-      uint32_t* dst = reinterpret_cast<uint32_t*>(smem + (size_t)r * PERSIST_RULES_BYTES);
-      for (int i = threadIdx.x; i < (int)(sizeof(ScsRules) / 4); i += PERSIST_GAMES * 4 * 64) dst[i] = src[i];
-    }
-    if (threadIdx.x < PERSIST_GAMES * 8)
-      reinterpret_cast<int*>(smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)(threadIdx.x >> 3) * q.wave_bytes + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES)[threadIdx.x & 7] = 0;
-  }
-  __syncthreads();
-  unsigned char* const wb = smem + (size_t)n_rules * PERSIST_RULES_BYTES + (size_t)slot * q.wave_bytes;
-  int* const flags = reinterpret_cast<int*>(wb + PERSIST_GAME_BYTES - PERSIST_FLAG_BYTES);
-  int* const go = flags + 4;
-  const int g = blockIdx.x * PERSIST_GAMES + slot;
-  if (leader) {
-    if (g < p.n_games) persist_leader<HEX, 4, CH>(p, q, R, wb, g, lane, flags, go);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(go, PERSIST_EXIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return;
-  }
-  // helper: one tile of every layer of every network pass of its game, asleep in between
-  float* const net = reinterpret_cast<float*>(wb + PERSIST_GAME_BYTES);
-  typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
-  constexpr int HDR_DWORDS = (int)(offsetof(Fused16Program, ops) / 4);
-  const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
-#define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
-  const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
-#undef PHDR
-  int seq = 0, pass = 0;
-  for (;;) {
-    int gv;
-    while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(8);
-    if (gv == PERSIST_EXIT) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    pass = gv;
-    quad_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, role, flags, seq);
   }
 }
 
@@ -1772,11 +1761,7 @@ __global__ __launch_bounds__(64) void compact_kernel(SearchParams p) {
 // the persistent kernel for a network (square / hexagonal taps), wavefronts per game and the game's children bound
 // (at most 64 legal actions per position: the expansion handles one chunk of children instead of four)
 typedef void (*persist_fn_t)(SearchParams, PersistArgs);
-persist_fn_t persist_pick(bool hex, int wpg, bool one_chunk) {
-  if (wpg == 4) {
-    if (hex) return one_chunk ? persist_kernel4<true, 1> : persist_kernel4<true, MAXC_CHUNKS>;
-    return one_chunk ? persist_kernel4<false, 1> : persist_kernel4<false, MAXC_CHUNKS>;
-  }
+persist_fn_t persist_pick(bool hex, bool one_chunk) {
   if (hex) return one_chunk ? persist_kernel<true, 1> : persist_kernel<true, MAXC_CHUNKS>;
   return one_chunk ? persist_kernel<false, 1> : persist_kernel<false, MAXC_CHUNKS>;
 }
@@ -2196,7 +2181,6 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
   bool persist = false;
   size_t persist_lds = 0;
   h->persist_used = 0;
-  static const int persist_wpg = getenv("NZ_SCS_PERSIST_WPG") ? atoi(getenv("NZ_SCS_PERSIST_WPG")) : 2;   // wavefronts per game: 2 or 4
   {
     static const int env_mode = getenv("NZ_SCS_PERSIST") ? atoi(getenv("NZ_SCS_PERSIST")) : -1;       // A/B experiments
     const int mode = h->persist_mode >= 0 ? h->persist_mode : env_mode;
@@ -2214,7 +2198,7 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
       persist_lds = (size_t)(q.rules_per_game ? PERSIST_GAMES : 1) * PERSIST_RULES_BYTES + (size_t)PERSIST_GAMES * q.wave_bytes;
       if (persist_lds > 160 * 1024) h->persist_why = "four games' blocks do not fit in LDS";
       else {
-        h->persist_fn = persist_pick(wn.hex != 0, persist_wpg, h->p.maxc <= 64);
+        h->persist_fn = persist_pick(wn.hex != 0, h->p.maxc <= 64);
         const hipError_t e = hipFuncSetAttribute((const void*)h->persist_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)persist_lds);
         if (e != hipSuccess) { (void)hipGetLastError(); h->persist_why = "hipFuncSetAttribute failed"; }
         else { persist = true; h->persist_why.clear(); }
@@ -2368,7 +2352,7 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
         S_HIP(h, hipEventRecord(h->ev_p0, s));
       }
       const dim3 pgrid((G + PERSIST_GAMES - 1) / PERSIST_GAMES);
-      hipLaunchKernelGGL(h->persist_fn, pgrid, dim3((persist_wpg == 4 ? 4 : 2) * PERSIST_GAMES * 64), persist_lds, s, h->p, h->pq);
+      hipLaunchKernelGGL(h->persist_fn, pgrid, dim3(PERSIST_THREADS), persist_lds, s, h->p, h->pq);
       S_HIP(h, hipGetLastError());
       ++h->waves;
       static const bool move_times = getenv("NZ_SCS_MOVE_TIMES") != nullptr;     // experiment: the duration of every move's launch
