@@ -117,6 +117,40 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 template <typename T>
 __device__ __forceinline__ T wave_get(T v, int lane) { return __shfl(v, lane, 64); }
 
+// Wavefront-wide max over (score, key) tuples, the larger key winning a tie (Explorer.py:100: max over (score, action,
+// child) tuples; key = action << 8 | child index).  Inside each 16-lane row two butterflies of DPP rotations (the maximum
+// score, then the largest key among the lanes that hold it), then the four rows' results meet through v_readlane: no
+// trip through the LDS crossbar (six rounds of three ds_bpermute were a thousand cycles per tree level).  Lanes without
+// a child pass score = -inf, key = -1.  Returns the winning key in every lane.
+template <int N>
+__device__ __forceinline__ int dpp_row_ror(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + N, 0xF, 0xF, false); }
+template <int N>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+  return __hiloint2double(dpp_row_ror<N>(__double2hiint(v)), dpp_row_ror<N>(__double2loint(v)));
+}
+__device__ __forceinline__ int wave_argmax_key(double score, int key) {
+  double m = score;
+  m = fmax(m, dpp_row_ror<8>(m));
+  m = fmax(m, dpp_row_ror<4>(m));
+  m = fmax(m, dpp_row_ror<2>(m));
+  m = fmax(m, dpp_row_ror<1>(m));
+  int win = (score == m) ? key : -1;
+  win = max(win, dpp_row_ror<8>(win));
+  win = max(win, dpp_row_ror<4>(win));
+  win = max(win, dpp_row_ror<2>(win));
+  win = max(win, dpp_row_ror<1>(win));
+  double best = -INFINITY;
+  int best_key = -1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double mr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 16 * r),
+                                       __builtin_amdgcn_readlane(__double2loint(m), 16 * r));
+    const int kr = __builtin_amdgcn_readlane(win, 16 * r);
+    if (mr > best || (mr == best && kr > best_key)) { best = mr; best_key = kr; }
+  }
+  return best_key;
+}
+
 // score of one child (Explorer.score, :114-130) in the reference's dtypes
 __device__ __forceinline__ double child_score(const SearchParams& p, const SNode& c, double sq, double cb, bool negate) {
   const double u = sq / (double)(c.visit + 1);
@@ -592,12 +626,7 @@ __global__ __launch_bounds__(64) void wave_kernel(SearchParams p, int mode, cons
         }
       }
       const int my_key = key;
-      // max over (score, action): the larger action wins a tie (Explorer.py:100)
-      for (int w = 32; w >= 1; w >>= 1) {
-        const double os = __shfl_xor(score, w, 64);
-        const int ok = __shfl_xor(key, w, 64);
-        if (os > score || (os == score && ok > key)) { score = os; key = ok; }
-      }
+      key = wave_argmax_key(score, key);          // max over (score, action): the larger action wins a tie (Explorer.py:100)
       // the lane that scored the winner (keys are unique: they carry the child index)
       const unsigned long long holders = __ballot(my_key == key);
       const int wl = __builtin_amdgcn_readfirstlane(__ffsll((long long)holders) - 1);
@@ -1198,11 +1227,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         }
       }
       const int my_key = key;
-      for (int w = 32; w >= 1; w >>= 1) {
-        const double os = __shfl_xor(score, w, 64);
-        const int ok = __shfl_xor(key, w, 64);
-        if (os > score || (os == score && ok > key)) { score = os; key = ok; }
-      }
+      key = wave_argmax_key(score, key);
       const unsigned long long holders = __ballot(my_key == key);
       const int wl = __builtin_amdgcn_readfirstlane(__ffsll((long long)holders) - 1);
       node = par_base + (key & 0xff);
