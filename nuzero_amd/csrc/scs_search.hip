@@ -912,6 +912,85 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
   }
 }
 
+// wave_epilogue for both row tiles of a column tile at once: the eight values go through every step together (one
+// wave-uniform switch, independent chains the scheduler interleaves; v_perm packs two values' upper halves per piece),
+// the stores are predicated per row tile.  Same values as wave_epilogue, piece for piece.
+__device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __restrict__ net, const Fused16Op& op, int ct,
+                                               int lane, int rows) {
+  const int c0 = ct * 16 + (lane >> 4) * 4;
+  int orow[2], chunk[2];
+  bool ok[2];
+  float v[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    orow[rt] = rt * 16 + (lane & 15);
+    ok[rt] = orow[rt] < rows;
+    chunk[rt] = (((c0 >> 3) ^ ((orow[rt] >> 2) & 3)) << 2) + ((c0 & 7) >> 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[rt][r] = acc[rt][r];
+  }
+  if (op.offr >= 0) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      if (ok[rt]) {
+        const float* rp = net + op.offr + orow[rt] * op.csr + chunk[rt];
+        const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + op.psr),
+                    q2 = *reinterpret_cast<const uint2*>(rp + 2 * op.psr);
+        auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
+        auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
+        v[rt][0] += (lo(q0.x) + lo(q1.x)) + lo(q2.x);
+        v[rt][1] += (hi(q0.x) + hi(q1.x)) + hi(q2.x);
+        v[rt][2] += (lo(q0.y) + lo(q1.y)) + lo(q2.y);
+        v[rt][3] += (hi(q0.y) + hi(q1.y)) + hi(q2.y);
+      }
+    }
+  }
+  switch (op.act) {
+    case 1:
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i >> 2][i & 3] = v[i >> 2][i & 3] > 0.f ? v[i >> 2][i & 3] : 0.f;
+      break;
+    case 2:
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i >> 2][i & 3] = tanhf(v[i >> 2][i & 3]);
+      break;
+    case 3:
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i >> 2][i & 3] = v[i >> 2][i & 3] > 0.f ? v[i >> 2][i & 3] : fast_expm1(v[i >> 2][i & 3]);
+      break;
+    default: break;
+  }
+  if (op.psd == 0) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      if (ok[rt]) *reinterpret_cast<f32x4*>(net + op.offd + orow[rt] * op.csd + c0) = f32x4{v[rt][0], v[rt][1], v[rt][2], v[rt][3]};
+    return;
+  }
+  uint2 q[2][3];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = v[rt][i];
+#pragma unroll
+    for (int piece = 0; piece < 3; ++piece) {
+      q[rt][piece] = uint2{wide_pack_hi16(r[0], r[1]), wide_pack_hi16(r[2], r[3])};
+      if (piece < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = r[i] - wide_trunc(r[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt) {
+    if (ok[rt]) {
+      float* dp = net + op.offd + orow[rt] * op.csd + chunk[rt];
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) *reinterpret_cast<uint2*>(dp + piece * op.psd) = q[rt][piece];
+    }
+  }
+}
+
 template <int NTAPS, int KGT, int RT = 2>
 __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* __restrict__ net, const Fused16Op& op,
                                                  const int (&srow)[RT][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
@@ -1012,8 +1091,7 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
       if (ct + 2 < op.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)(ct + 2) * op.w_chunks * 4, op.w_chunks), lane * 16);
       else if (o + 1 < n_ops && half < next.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(next.w + (size_t)half * next.w_chunks * 4, next.w_chunks), lane * 16);
 #endif
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt) wave_epilogue(acc[rt], net, op, rt, ct, lane, rows);
+      wave_epilogue2(acc, net, op, ct, lane, rows);
       WSTAMP(1);
     }
 #if NZ_PERSIST_XOP
