@@ -489,11 +489,13 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
 // Scs::step by a whole wavefront: lane 0 applies the action (a handful of stores), the turn
 // machine's "is any unit of player p queued / available / moved" scans (update_game_env,
 // :687-831) become one ballot each instead of a loop over the units.
+// (`tiles_magic` = ceil(2^32 / tiles), or 0: action / tiles by one multiply-high instead of an integer division -- exact
+// for the action indices of a board of <= 100 tiles; a tree descent makes this step once per level)
 template <bool ONEWAVE = true>
-__device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, int action, int lane) {
+__device__ __forceinline__ void scs_step_wave(const ScsRules& r, ScsState& s, int action, int lane, uint32_t tiles_magic = 0u) {
   Scs game(r, s);
   const int T = r.tiles, S = r.stacking;
-  const int plane = action / T, t = action % T;
+  const int plane = tiles_magic ? (int)__umulhi((uint32_t)action, tiles_magic) : action / T, t = action - plane * T;
   const bool unit_lane = lane < r.n_units;
   const int pl = unit_lane ? r.u_player[lane] : -1, tu = unit_lane ? r.u_turn[lane] : -1;
   int st = unit_lane ? s.status[lane] : 99;

@@ -202,10 +202,11 @@ __device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, c
       racc += lane8 == ((ix - lo) & 7) ? v : 0.f;
       ++i;
     }
-    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), read from lane 0
-    const float t1 = racc + __shfl_xor(racc, 1, 64);
-    const float t2 = t1 + __shfl_xor(t1, 2, 64);
-    const float t3 = t2 + __shfl_xor(t2, 4, 64);
+    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), read from lane 0: lane i takes lane i + 1 / + 2 / + 4 of its
+    // row by DPP shifts (only lane 0's chain matters; no trip through the LDS crossbar)
+    const float t1 = racc + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, racc), 0x101, 0xF, 0xF, false));   // row_shl:1
+    const float t2 = t1 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x102, 0xF, 0xF, false));       // row_shl:2
+    const float t3 = t2 + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t2), 0x104, 0xF, 0xF, false));       // row_shl:4
     float res = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t3)));
     while (i < k) {
       if (entry_idx(i) >= hi) break;
@@ -1252,6 +1253,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   scs_sync<false>();
   unsigned long long n_sim = 0, n_exp = 0, n_hit = 0, n_miss = 0;
   bool failed = false;
+  const uint32_t tiles_magic = 0xFFFFFFFFu / (uint32_t)hw + 1u;       // ceil(2^32 / tiles) for scs_step_wave (exact for every action index of boards of <= 100 tiles: checked exhaustively on the host, tests/test_host_logic.py)
 #ifdef NZ_PERSIST_STAMPS   // diagnostic build: where a game's time goes (nz_scs_search_persist_ticks)
   unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
   const unsigned long long t_begin = ts;
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       if (par_k > 0) fetch_level();
       if (plen < 64) { if (lane == plen) my_path = node; }
       else if (lane == 0) path[plen] = node;
-      scs_step_wave<false>(R, sc, key >> 8, lane);
+      scs_step_wave<false>(R, sc, key >> 8, lane, tiles_magic);
       ++plen;
     }
     if (bad) {

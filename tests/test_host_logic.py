@@ -491,3 +491,12 @@ def test_gamer_without_records_refuses_a_host_replay_buffer():
     for game, args in ((tic_tac_toe, []), (SCS_Game, ["x.yml"])):
         with pytest.raises(ValueError, match="records=False"):
             Gamer(ReplayBuffer(10, 4), None, game, args, 0, legacy_ttt_search_config(25), 2, num_games=4, records=False)
+
+
+def test_action_index_division_by_multiply_high():
+    """scs_step_wave splits an action index into (plane, tile) with one multiply-high by ceil(2^32 / tiles)
+    (scs_dev.hpp): exact for every board of <= 100 tiles and every action index the engine admits (21 planes x tiles)."""
+    for tiles in range(1, 101):
+        magic = 0xFFFFFFFF // tiles + 1
+        a = np.arange(0, 21 * 100 + 1, dtype=np.uint64)
+        assert np.array_equal((a * np.uint64(magic)) >> np.uint64(32), a // np.uint64(tiles)), tiles
