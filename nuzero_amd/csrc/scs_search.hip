@@ -22,6 +22,9 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -2222,6 +2225,66 @@ nz_status nz_scs_search_play(nz_scs_search* h, nz_boardnet* net, const uint32_t*
 }  // extern "C"
 
 namespace {
+// page-locked host array (the move loop's read-backs and uploads: from pageable memory every copy is staged)
+template <typename T>
+struct Pinned {
+  T* p = nullptr;
+  size_t n = 0;
+  explicit Pinned(size_t count) : n(count) {
+    if (hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) p = nullptr;
+  }
+  ~Pinned() { if (p) (void)hipHostFree(p); }
+  Pinned(const Pinned&) = delete;
+  Pinned& operator=(const Pinned&) = delete;
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* data() { return p; }
+  size_t size() const { return n; }
+};
+// a few host threads that live for one play call: every move hands them the same job (the games' random draws, a slice
+// of the games each) -- starting and joining eight threads per move was a quarter of a millisecond of every move
+class WorkerPool {
+ public:
+  explicit WorkerPool(int n) {
+    for (int t = 0; t < n; ++t) threads_.emplace_back([this, t] { loop(t); });
+  }
+  ~WorkerPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (std::thread& t : threads_) t.join();
+  }
+  int size() const { return (int)threads_.size(); }
+  void run(const std::function<void(int)>& job) {            // job(thread index) on every thread; returns when all are done
+    { std::lock_guard<std::mutex> lk(m_); job_ = &job; pending_ = (int)threads_.size(); ++generation_; }
+    cv_.notify_all();
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [this] { return pending_ == 0; });
+  }
+ private:
+  void loop(int t) {
+    long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* job;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        job = job_;
+      }
+      (*job)(t);
+      { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  long generation_ = 0;
+  int pending_ = 0;
+  bool stop_ = false;
+};
+
 // (re)allocate the round's store for `n` games
 nz_status round_store(nz_scs_search* h, int64_t n) {
   if (n <= h->round_capacity) return NZ_OK;
@@ -2346,8 +2409,11 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     S_HIP(h, hipMemcpyAsync(h->rules_row_dev, rules_rows.data(), (size_t)G * sizeof(int32_t), hipMemcpyHostToDevice, (hipStream_t)stream));
     S_HIP(h, hipStreamSynchronize((hipStream_t)stream));
   }
-  std::vector<int32_t> status((size_t)G * 7), nchild(G);
-  std::vector<double> noise((size_t)G * MAXC), uni((size_t)G * 3);
+  Pinned<int32_t> status((size_t)G * 7), nchild(G);
+  Pinned<double> noise((size_t)G * MAXC), uni((size_t)G * 3);
+  if (!status.p || !nchild.p || !noise.p || !uni.p) return sfail(h, NZ_ERR_HIP, "host allocation failed");
+  const int n_thr = h->cfg.training && G >= 256 ? std::min<int>(8, std::max<unsigned>(1u, std::thread::hardware_concurrency())) : 0;
+  WorkerPool pool(n_thr);
   nz_status st = nz_scs_search_reset(h, stream);
   if (st != NZ_OK) return st;
   h->waves = 0;
@@ -2414,8 +2480,8 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
     for (int g = 0; g < G; ++g) any |= status[(size_t)g * 7 + 4] == 0;
     if (!any) break;
     if (h->cfg.training) {
-      std::fill(noise.begin(), noise.end(), 0.0);
-      std::fill(uni.begin(), uni.end(), 0.0);
+      std::fill(noise.data(), noise.data() + noise.size(), 0.0);
+      std::fill(uni.data(), uni.data() + uni.size(), 0.0);
       // (every game has its own stream: the draws of different games run on host threads side by side)
       auto draw = [&](int g0, int g1) {
         for (int g = g0; g < g1; ++g) {
@@ -2432,14 +2498,8 @@ nz_status play_impl(nz_scs_search* h, nz_boardnet* net, const uint32_t* seeds_ho
           }
         }
       };
-      const int n_thr = G >= 256 ? std::min<int>(8, std::max<unsigned>(1u, std::thread::hardware_concurrency())) : 1;
-      if (n_thr <= 1) {
-        draw(0, G);
-      } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_thr; ++t) pool.emplace_back(draw, (int)((int64_t)G * t / n_thr), (int)((int64_t)G * (t + 1) / n_thr));
-        for (std::thread& t : pool) t.join();
-      }
+      if (n_thr <= 1) draw(0, G);
+      else pool.run([&](int t) { draw((int)((int64_t)G * t / n_thr), (int)((int64_t)G * (t + 1) / n_thr)); });
       S_HIP(h, hipMemcpyAsync(h->noise, noise.data(), noise.size() * sizeof(double), hipMemcpyHostToDevice, s));
       S_HIP(h, hipMemcpyAsync(h->uniforms, uni.data(), uni.size() * sizeof(double), hipMemcpyHostToDevice, s));
     }
