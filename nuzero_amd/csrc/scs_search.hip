@@ -922,6 +922,9 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
 __device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __restrict__ net, const Fused16Op& op, int ct,
                                                int lane, int rows) {
   const int c0 = ct * 16 + (lane >> 4) * 4;
+#ifdef NZ_ABL_PERSIST_NOEPI   // timing experiment: no epilogue (results wrong)
+  if (acc[0][0] != 12345.678f) return;
+#endif
   int orow[2], chunk[2];
   bool ok[2];
   float v[2][4];
