@@ -800,6 +800,9 @@ __device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, 
 #ifndef NZ_PERSIST_AHEAD
 #define NZ_PERSIST_AHEAD 3
 #endif
+#ifndef NZ_PERSIST_PAIRED
+#define NZ_PERSIST_PAIRED 0       // 1: a step's MFMAs in a fixed order behind its loads (wave_conv)
+#endif
 constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
 // the first WAVE_AHEAD steps' weights of a column tile's stream (steps are contiguous whatever the layer's K groups)
 // (buffer loads: a wave-uniform descriptor of the column tile's stream, ONE vector register with this lane's byte offset,
@@ -807,23 +810,32 @@ constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_weights_rsrc(const uint32_t* wg, int chunks16) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wg), (short)0, chunks16 * 16, 0x00020000);
 }
-__device__ __forceinline__ u32x4 wave_weights_load(__amdgpu_buffer_rsrc_t rs, int voff, int st, int piece) {
+// one step's three pieces; the stream position is ONE running vector register (the step's 3 KB added after its loads, the
+// pieces as immediate offsets): a scalar offset per (step, piece) was forty scalar registers of constants held across
+// the whole pass, and the layer's own scalars went to spill lanes for them
+__device__ __forceinline__ void wave_weights_step(u32x4 (&dst)[3], __amdgpu_buffer_rsrc_t rs, int& wv) {
+#pragma unroll
+  for (int piece = 0; piece < 3; ++piece) {
 #ifdef NZ_ABL_PERSIST_NOB      // timing experiment: no weight stream (results wrong)
-  return u32x4{(uint32_t)(voff & 0), (uint32_t)(st & 0), (uint32_t)(piece & 0), 0u};       // (zeros: finite activations)
+    dst[piece] = u32x4{(uint32_t)(wv & 0), (uint32_t)(piece & 0), 0u, 0u};       // (zeros: finite activations)
 #else
-  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (st * 3 + piece) * 1024, 0));
+    dst[piece] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, wv + piece * 1024, 0, 0));
 #endif
+  }
+  wv += 3072;
+  asm volatile("" : "+v"(wv));
 }
-__device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1][3], __amdgpu_buffer_rsrc_t rs, int voff) {
+__device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1][3], __amdgpu_buffer_rsrc_t rs, int& wv, int lane) {
+  wv = lane * 16;
+  asm volatile("" : "+v"(wv));
 #pragma unroll
-  for (int st = 0; st < WAVE_AHEAD; ++st)
-#pragma unroll
-    for (int piece = 0; piece < 3; ++piece) bq[st][piece] = wave_weights_load(rs, voff, st, piece);
+  for (int st = 0; st < WAVE_AHEAD; ++st) wave_weights_step(bq[st], rs, wv);
 }
 template <int NTAPS, int KGT, int RT = 2>
 __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restrict__ net, const int (&srow)[RT][NTAPS],
-                                          int off0, int cs0, int ps0, int kq, __amdgpu_buffer_rsrc_t wrs, int voff,
-                                          u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
+                                          int off0, int cs0, int ps0, int kq, __amdgpu_buffer_rsrc_t wrs, int& wv,
+                                          u32x4 (&bq)[WAVE_AHEAD + 1][3], unsigned long long* tkn = nullptr,
+                                          unsigned long long* tsn = nullptr) {
   constexpr int STEPS = NTAPS * KGT;
   constexpr int AHEAD = WAVE_AHEAD;
   static_assert(STEPS >= AHEAD, "the prologue is always AHEAD steps");
@@ -833,7 +845,7 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restr
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const int r = srow[rt][tap];
-      const int a0 = off0 + r * cs0 + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
+      const int a0 = off0 + (int)__umul24((unsigned)r, (unsigned)cs0) + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
 #pragma unroll
       for (int piece = 0; piece < 3; ++piece) {
 #ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
@@ -845,22 +857,46 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restr
     }
   };
   load_a(0, a[0]);
+#ifdef NZ_PERSIST_HEADSTAMP   // diagnostic: how long a layer waits for its first operands (slot 3; perturbs the pipeline)
+  if (tkn) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    tkn[3] += now - *tsn;
+    *tsn = now;
+  }
+#endif
 #pragma unroll
   for (int st = 0; st < STEPS; ++st) {
     if (st + 1 < STEPS) load_a(st + 1, a[(st + 1) & 1]);
-    if (st + AHEAD < STEPS) {
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece)
-        bq[(st + AHEAD) % (AHEAD + 1)][piece] = wave_weights_load(wrs, voff, st + AHEAD, piece);
-    }
+    if (st + AHEAD < STEPS) wave_weights_step(bq[(st + AHEAD) % (AHEAD + 1)], wrs, wv);
 #ifdef NZ_ABL_PERSIST_EARLYLDS
     // experiment (not kept): force the next step's operand reads out BEFORE this step's MFMAs -- the pass alone 86.7 k
     // ticks against 81.9 k, the round 775 against 970 games/s (longer live ranges, 54 spilled registers)
     __builtin_amdgcn_sched_barrier(0);
 #endif
+#if NZ_PERSIST_PAIRED
+    if constexpr (RT == 2) {
+      // The step's loads go out FIRST and its twelve MFMAs follow as six pairs (row tile 0, row tile 1) in step16's term
+      // order: left to itself the scheduler put the operand reads of step st + 1 behind the MFMAs of step st (their
+      // latency then sits at the head of every step: a third of the pass), and told to put them first it ran each row
+      // tile's six dependent MFMAs as one chain (every one waits for the one before it).
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 (&b)[3] = bq[st % (AHEAD + 1)];
+      const u32x4 (&a0)[3] = a[st & 1][0];
+      const u32x4 (&a1)[3] = a[st & 1][1];
+#define NZ_PAIR(B, A)                         \
+  acc[0] = wide_mfma(b[B], a0[A], acc[0]);    \
+  acc[1] = wide_mfma(b[B], a1[A], acc[1]);    \
+  __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(1, 1) NZ_PAIR(0, 2) NZ_PAIR(2, 0) NZ_PAIR(0, 1) NZ_PAIR(1, 0) NZ_PAIR(0, 0)
+#undef NZ_PAIR
+    } else
+#endif
+    {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
-    __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
+      for (int rt = 0; rt < RT; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
+      __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
+    }
   }
 }
 
@@ -1000,19 +1036,16 @@ __device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __r
 
 template <int NTAPS, int KGT, int RT = 2>
 __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* __restrict__ net, const Fused16Op& op,
-                                                 const int (&srow)[RT][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3]) {
+                                                 const int (&srow)[RT][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3],
+                                                 int& wv, unsigned long long* tkn = nullptr, unsigned long long* tsn = nullptr) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
   // (an opaque k-quarter: the operand addresses of every step of every variant are loop-invariant arithmetic, and hoisted
   // out of the layer loop they are 180 live registers)
   int kq = lane >> 4;
   asm volatile("" : "+v"(kq));
-  const int voff = lane * 16;
   const __amdgpu_buffer_rsrc_t wrs = wave_weights_rsrc(op.w + (size_t)ct * op.w_chunks * 4, op.w_chunks);
-#if !NZ_PERSIST_XOP
-  wave_weights_prologue(bq, wrs, voff);
-#endif
-  wave_conv<NTAPS, KGT, RT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, voff, bq);
+  wave_conv<NTAPS, KGT, RT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, wv, bq, tkn, tsn);
 }
 
 // The two wavefronts of a game meet (the leader runs the tree and half of every layer, the helper the other half): each
@@ -1020,7 +1053,7 @@ __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* 
 // order, so the partner that sees the number sees the activations stored before it.
 __device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane) {
   ++seq;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // (LDS only: everything a pair shares is in LDS)
   if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef NZ_PERSIST_SYNC_SLEEP
 #define NZ_PERSIST_SYNC_SLEEP 0
@@ -1028,7 +1061,7 @@ __device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane
   while (__hip_atomic_load(&flags[me ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) {
     if (NZ_PERSIST_SYNC_SLEEP > 0) __builtin_amdgcn_s_sleep(NZ_PERSIST_SYNC_SLEEP);
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // every layer of the network for the position whose input pieces sit in the game's block: this wavefront takes the
@@ -1070,44 +1103,97 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
     for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(v, i);
     __builtin_memcpy(&op, words, sizeof(Fused16Op));
   };
-  // The weights of a (layer, column tile) job's first steps are fetched while the job before it finishes (its epilogue,
-  // the meeting of the two wavefronts): an L2 round trip at the head of every layer is most of a layer otherwise.
-  Fused16Op op, next;
-  unpack(lane < OP_DWORDS ? ops_words[lane] : 0u, op);
-  uint32_t dvec = (n_ops > 1 && lane < OP_DWORDS) ? ops_words[OP_DWORDS + lane] : 0u;
-#if NZ_PERSIST_XOP
+  // A layer's descriptor stays in ONE vector register (a dword per lane, fetched a layer ahead) until the layer starts:
+  // unpacked a layer early its fields were scalar registers the K loop had no room for (spilled to lanes and back).
+  uint32_t cur = lane < OP_DWORDS ? ops_words[lane] : 0u;
+  uint32_t nxt = (n_ops > 1 && lane < OP_DWORDS) ? ops_words[OP_DWORDS + lane] : 0u;
+  int wv = 0;
+  // This wavefront's jobs of a layer: column tiles half, half + 2, ... of the layer's PAIRS of column tiles (both row
+  // tiles each), then row tile `half` of an odd last column tile (whole it was the leader's alone and the helper waited).
   u32x4 bq[WAVE_AHEAD + 1][3];
-  if (half < op.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)half * op.w_chunks * 4, op.w_chunks), lane * 16);
+  auto job_weights = [&](const Fused16Op& x, int ct) {
+    wave_weights_prologue(bq, wave_weights_rsrc(x.w + (size_t)ct * x.w_chunks * 4, x.w_chunks), wv, lane);
+  };
+  [[maybe_unused]] auto first_job = [&](const Fused16Op& x) { return half < (x.ntiles & ~1) ? half : x.ntiles - 1; };
+#if NZ_PERSIST_XOP
+  // A job's first weights are fetched while the job before it finishes (XOP 1: under its epilogue and the meeting, 2: under
+  // the meeting and the next layer's header only): an L2 round trip at the head of every layer otherwise.  (The meeting
+  // orders LDS only: a fence over global memory too would wait for these loads.)
+  {
+    Fused16Op first;
+    unpack(cur, first);
+    job_weights(first, first_job(first));
+  }
 #endif
   for (int o = 0; o < n_ops; ++o) {
-    if (o + 1 < n_ops) unpack(dvec, next);
-    if (o + 2 < n_ops && lane < OP_DWORDS) dvec = ops_words[(o + 2) * OP_DWORDS + lane];
-    const int kgt = op.kg0;
-    for (int ct = half; ct < op.ntiles; ct += 2) {
-      f32x4 acc[2];
-#if !NZ_PERSIST_XOP
-      u32x4 bq[WAVE_AHEAD + 1][3];
-#endif
-      if (kgt == 1) wave_layer_kloop<ntaps, 1>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 2) wave_layer_kloop<ntaps, 2>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 3) wave_layer_kloop<ntaps, 3>(acc, net, op, srow, ct, lane, bq);
-      else wave_layer_kloop<ntaps, 4>(acc, net, op, srow, ct, lane, bq);
-      WSTAMP(0);
+    Fused16Op op;
+    unpack(cur, op);
+    cur = nxt;
+    if (o + 2 < n_ops && lane < OP_DWORDS) nxt = ops_words[(o + 2) * OP_DWORDS + lane];
 #if NZ_PERSIST_XOP
-      // the next job's first weights: this layer's next column tile of mine, else the next layer's first
-      if (ct + 2 < op.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)(ct + 2) * op.w_chunks * 4, op.w_chunks), lane * 16);
-      else if (o + 1 < n_ops && half < next.ntiles) wave_weights_prologue(bq, wave_weights_rsrc(next.w + (size_t)half * next.w_chunks * 4, next.w_chunks), lane * 16);
+    Fused16Op next;
+    unpack(cur, next);               // (only w, w_chunks, ntiles are read)
+#endif
+    const int kgt = op.kg0;
+    const int pair_tiles = op.ntiles & ~1;
+    const bool odd = op.ntiles & 1;
+    for (int ct = half; ct < pair_tiles; ct += 2) {
+      f32x4 acc[2];
+      WSTAMP(4);                    // (the layer's header: descriptor words, addresses)
+#if !NZ_PERSIST_XOP
+      job_weights(op, ct);
+#endif
+#ifdef NZ_PERSIST_STAMPS
+      if (kgt == 1) wave_layer_kloop<ntaps, 1>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
+      else wave_layer_kloop<ntaps, 4>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
+#else
+      if (kgt == 1) wave_layer_kloop<ntaps, 1>(acc, net, op, srow, ct, lane, bq, wv);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2>(acc, net, op, srow, ct, lane, bq, wv);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3>(acc, net, op, srow, ct, lane, bq, wv);
+      else wave_layer_kloop<ntaps, 4>(acc, net, op, srow, ct, lane, bq, wv);
+#endif
+      WSTAMP(0);
+#if NZ_PERSIST_XOP == 1
+      if (ct + 2 < pair_tiles) job_weights(op, ct + 2);
+      else if (odd) job_weights(op, op.ntiles - 1);
+      else if (o + 1 < n_ops) job_weights(next, first_job(next));
 #endif
       wave_epilogue2(acc, net, op, ct, lane, rows);
+#if NZ_PERSIST_XOP == 2
+      if (ct + 2 < pair_tiles) job_weights(op, ct + 2);
+      else if (odd) job_weights(op, op.ntiles - 1);
+      else if (o + 1 < n_ops) job_weights(next, first_job(next));
+#endif
       WSTAMP(1);
     }
-#if NZ_PERSIST_XOP
-    if (half >= op.ntiles && o + 1 < n_ops && half < next.ntiles)      // (a layer with no tile for this half)
-      wave_weights_prologue(bq, wave_weights_rsrc(next.w + (size_t)half * next.w_chunks * 4, next.w_chunks), lane * 16);
+    if (odd) {
+      const int ct = op.ntiles - 1;
+      int srow1[1][ntaps];
+#pragma unroll
+      for (int tap = 0; tap < ntaps; ++tap) srow1[0][tap] = half ? srow[1][tap] : srow[0][tap];
+      f32x4 acc[1];
+      WSTAMP(4);
+#if !NZ_PERSIST_XOP
+      job_weights(op, ct);
 #endif
+      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow1, ct, lane, bq, wv);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow1, ct, lane, bq, wv);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow1, ct, lane, bq, wv);
+      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow1, ct, lane, bq, wv);
+      WSTAMP(0);
+#if NZ_PERSIST_XOP == 1
+      if (o + 1 < n_ops) job_weights(next, first_job(next));
+#endif
+      wave_epilogue(acc[0], net, op, half, ct, lane, rows);
+#if NZ_PERSIST_XOP == 2
+      if (o + 1 < n_ops) job_weights(next, first_job(next));
+#endif
+      WSTAMP(1);
+    }
     pair_sync(flags, half, seq, lane);     // the layer is whole before either half reads it (or overwrites its source)
     WSTAMP(2);
-    op = next;
   }
 }
 
@@ -1156,10 +1242,12 @@ __device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ 
     for (int ct = half; ct < op.ntiles; ct += 2) {
       f32x4 acc[1];
       u32x4 bq[WAVE_AHEAD + 1][3];
-      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow, ct, lane, bq);
-      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow, ct, lane, bq);
-      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow, ct, lane, bq);
+      int wv = 0;
+      wave_weights_prologue(bq, wave_weights_rsrc(op.w + (size_t)ct * op.w_chunks * 4, op.w_chunks), wv, lane);
+      if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow, ct, lane, bq, wv);
+      else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow, ct, lane, bq, wv);
+      else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow, ct, lane, bq, wv);
+      else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow, ct, lane, bq, wv);
       wave_epilogue(acc[0], net, op, rt, ct, lane, rows);
     }
     quad_sync(flags, quad, seq, lane);
@@ -1257,11 +1345,11 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   const int pol_off = PHDR(pol_off), pp = PHDR(pol_cs), val_off = PHDR(val_off), vp = PHDR(val_cs);
 #undef PHDR
   scs_sync<false>();
-  unsigned long long n_sim = 0, n_exp = 0, n_hit = 0, n_miss = 0;
+  int n_sim = 0, n_exp = 0, n_hit = 0, n_miss = 0;      // (of this move: 32 bits are plenty, and half the registers)
   bool failed = false;
   const uint32_t tiles_magic = 0xFFFFFFFFu / (uint32_t)hw + 1u;       // ceil(2^32 / tiles) for scs_step_wave (exact for every action index of boards of <= 100 tiles: checked exhaustively on the host, tests/test_host_logic.py)
 #ifdef NZ_PERSIST_STAMPS   // diagnostic build: where a game's time goes (nz_scs_search_persist_ticks)
-  unsigned long long tk[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
+  unsigned long long tk[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts = __builtin_amdgcn_s_memtime();
   const unsigned long long t_begin = ts;
 #define PSTAMP(slot) { const unsigned long long now = __builtin_amdgcn_s_memtime(); tk[slot] += now - ts; ts = now; }
 #else
@@ -1589,10 +1677,10 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
     p.pending[g] = -1;
     p.node_count[g] = base;
     if (rec >= 0) q.rec_count[rec] = rec_n;
-    if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], n_sim);
-    if (n_exp) atomicAdd((unsigned long long*)&p.counters[1], n_exp);
-    if (n_hit) atomicAdd((unsigned long long*)&p.counters[8], n_hit);
-    if (n_miss) atomicAdd((unsigned long long*)&p.counters[9], n_miss);
+    if (n_sim) atomicAdd((unsigned long long*)&p.counters[0], (unsigned long long)n_sim);
+    if (n_exp) atomicAdd((unsigned long long*)&p.counters[1], (unsigned long long)n_exp);
+    if (n_hit) atomicAdd((unsigned long long*)&p.counters[8], (unsigned long long)n_hit);
+    if (n_miss) atomicAdd((unsigned long long*)&p.counters[9], (unsigned long long)n_miss);
   }
 }
 
@@ -1725,11 +1813,25 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
   int seq = 0;
   pair_sync(flags, leader ? 0 : 1, seq, lane);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-  const int active = iters >> 16 ? iters >> 16 : PERSIST_GAMES, n_it = iters & 0xffff;
+#ifdef NZ_PERSIST_STAMPS    // diagnostic build: iters bits 24.. = 1 + the phase whose ticks are reported instead of the pass
+  unsigned long long tkn[5] = {0, 0, 0, 0, 0};   // K loops, epilogues, meetings, first operands (HEADSTAMP), layer headers
+  const int phase = (iters >> 24) - 1;
+  const int active = (iters >> 16) & 0xff ? (iters >> 16) & 0xff : PERSIST_GAMES, n_it = iters & 0xffff;
+  if (slot < active)
+    for (int it = 0; it < n_it; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq, tkn);
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  unsigned long long rep = t1 - t0;
+  for (int k = 0; k < 5; ++k) if (phase == k) rep = tkn[k];
+  if (phase >= 8 && phase < 13) {              // phases 8..12: the HELPER's
+    if (!leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = tkn[phase - 8] / (unsigned long long)n_it;
+  } else if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = rep / (unsigned long long)n_it;
+#else
+  const int active = (iters >> 16) & 0xff ? (iters >> 16) & 0xff : PERSIST_GAMES, n_it = iters & 0xffff;
   if (slot < active)
     for (int it = 0; it < n_it; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq);
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)n_it;
+#endif
 }
 
 __global__ void search_status_kernel(SearchParams p, int32_t* out) {

@@ -17,6 +17,9 @@ from nuzero_amd.weights import synthetic_weights, convnet_param_shapes   # noqa:
 cfg = ScsGameConfig(os.path.join(REPO, "tests", "golden", "scs_configs", "mirrored_5x5.yml"))
 net = BoardNet("convnet", cfg.channels, cfg.planes, cfg.rows, cfg.cols, width=32, num_blocks=8, max_batch=1024)
 net.set_weights(synthetic_weights(0, convnet_param_shapes(cfg.channels, cfg.planes, 3, 32, 8)))
+phases = os.environ.get("NZ_NETBENCH_PHASES")   # stamped builds: also the ticks of each phase of the pass
+names = {0: "K loops", 1: "epilogues", 2: "meetings", 3: "first operands", 4: "layer headers",
+         8: "helper K loops", 9: "helper epilogues", 10: "helper meetings", 11: "helper first operands", 12: "helper layer headers"}
 for active in (4, 2, 1):               # game slots of a workgroup that run passes (the others stay idle)
     for blocks in (1, 256):
         out = np.zeros(blocks * 4, np.uint64)
@@ -24,3 +27,9 @@ for active in (4, 2, 1):               # game slots of a workgroup that run pass
         assert st == 0, st
         out = out.reshape(blocks, 4)[:, :active]
         print(f"{active} of 4 game slots, {blocks} workgroups: ticks per pass min {out.min()} median {int(np.median(out))} max {out.max()}")
+        if phases and blocks == 256:
+            for ph, name in names.items():
+                out = np.zeros(blocks * 4, np.uint64)
+                st = lib.nz_scs_netbench(net._h, blocks, 50 | (active << 16) | ((ph + 1) << 24), ctypes.c_void_p(out.ctypes.data))
+                assert st == 0, st
+                print(f"    {name}: median {int(np.median(out.reshape(blocks, 4)[:, :active]))}")
