@@ -1733,8 +1733,10 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
   for (const PackedConv& pc : h->convs)
     if (!pc.dev16 || pc.coutp > 64 || pc.kg0_32 > 4) return no("a layer is wider than 64 channels");
   const int rows = h->hw, R1 = rows + 1;
-  auto cs_of = [](int channels) { return (channels + 31) / 32 * 16; };
-  auto pieces_floats = [&](int channels) { return (size_t)3 * R1 * cs_of(channels); };
+  // pieces buffers: [row][32-channel group][piece][16 floats] (scs_search.hip, wave_conv); rows 256 bytes apart would
+  // share their LDS banks, so an even number of groups gets 16 floats of padding per row
+  auto cs_of = [](int channels) { const int kg = (channels + 31) / 32; return kg * 48 + (kg % 2 == 0 ? 16 : 0); };
+  auto pieces_floats = [&](int channels) { return (size_t)R1 * cs_of(channels); };
   const int W = nd.width;
   if (h->buffer_channels[4] > h->widthp || h->buffer_channels[6] > h->widthp) return no("head layers wider than the trunk");
   Fused16Program pg;
@@ -1754,10 +1756,10 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
   pg.n_ops = n_ops;
   pg.hw = h->hw; pg.h = h->rows; pg.wd = h->cols;
   pg.planes = nd.policy_channels; pg.hex = nd.hex ? 1 : 0;
-  pg.in_off = off_i; pg.in_cs = cs_of(h->inp); pg.in_ps = R1 * pg.in_cs;
+  pg.in_off = off_i; pg.in_cs = cs_of(h->inp); pg.in_ps = 16;
   pg.pol_off = off_i; pg.pol_cs = pol_cs;
   pg.val_off = off_i + (int)pol_floats; pg.val_cs = val_cs;
-  const int cs_w = cs_of(W), ps_w = R1 * cs_w;
+  const int cs_w = cs_of(W), ps_w = 16;
   struct Place { int off, cs, ps; };
   const Place in_pl{off_i, pg.in_cs, pg.in_ps};
   const Place trunk[4] = {in_pl, {off_t, cs_w, ps_w}, {off_t + (int)act, cs_w, ps_w}, {off_t + 2 * (int)act, cs_w, ps_w}};
@@ -1791,8 +1793,8 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
     f.ntiles = pc.coutp / 16; f.act = op.act;
     f.w_chunks = ntaps * pc.kg0_32 * 3 * 64;
     f.w_lds = 0; f.w_slot = 0; f.w_after_barrier = 0;
-    if (f.kg0 * 16 > f.cs0) return no("internal: K groups beyond the source rows");
-    if (dst.ps != 0 && f.ntiles * 8 > dst.cs) return no("internal: output tiles beyond the destination rows");
+    if (f.kg0 * 48 > f.cs0) return no("internal: K groups beyond the source rows");
+    if (dst.ps != 0 && (f.ntiles + 1) / 2 * 48 > dst.cs) return no("internal: output tiles beyond the destination rows");
   }
   Fused16Program* dev = nullptr;
   if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return no("device allocation failed");

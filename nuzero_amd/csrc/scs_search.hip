@@ -784,6 +784,9 @@ __device__ __forceinline__ void image_hash_wave(const float* stage, int inp, int
   lo = mix64(b ^ (a << 9));
 }
 
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 // the check word of a cache entry: per-lane sums of per-probability mixes (acc), the value and the key
 __device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, uint64_t key_hi, uint64_t key_lo) {
   for (int o = 32; o; o >>= 1) acc += __shfl_xor((unsigned long long)acc, o, 64);
@@ -798,12 +801,12 @@ __device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, 
 #define NZ_PERSIST_XOP 0          // 1: a job's first weights are fetched under the epilogue of the job before it
 #endif
 #ifndef NZ_PERSIST_AHEAD
-#define NZ_PERSIST_AHEAD 3
-#endif
-#ifndef NZ_PERSIST_PAIRED
-#define NZ_PERSIST_PAIRED 0       // 1: a step's MFMAs in a fixed order behind its loads (wave_conv)
+#define NZ_PERSIST_AHEAD 2
 #endif
 constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
+#ifndef NZ_PERSIST_SPREAD
+#define NZ_PERSIST_SPREAD 1       // 1: a K step's loads placed one per MFMA gap (wave_conv)
+#endif
 // the first WAVE_AHEAD steps' weights of a column tile's stream (steps are contiguous whatever the layer's K groups)
 // (buffer loads: a wave-uniform descriptor of the column tile's stream, ONE vector register with this lane's byte offset,
 // the step's offset as a scalar -- plain global loads keep a 64-bit address pair alive per load in flight, forty registers)
@@ -831,32 +834,68 @@ __device__ __forceinline__ void wave_weights_prologue(u32x4 (&bq)[WAVE_AHEAD + 1
 #pragma unroll
   for (int st = 0; st < WAVE_AHEAD; ++st) wave_weights_step(bq[st], rs, wv);
 }
+// Pieces buffers in a game's LDS block: [row][32-channel group][piece][four 16-byte chunks], a row every `cs` floats
+// (48 per group, + 16 when the groups are even in number: rows 256 bytes apart would share their banks), chunk q of row
+// r at position q ^ ((r >> 2) & 3).  A K step's operand reads are then ONE address per (row tile, tap) -- made once per
+// layer -- plus immediates (group x 192 + piece x 64 bytes): no address arithmetic between the MFMAs, whose gaps hide
+// eight cycles of other vector issue each and no more.
+constexpr int PIECE_FLOATS = 16, GROUP_FLOATS = 3 * PIECE_FLOATS;
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4;
+// this lane's operand rows of a position's conv taps, a byte per tap (four taps to a register): the row index (rows = the
+// buffers' row of zeros) in rows[], the byte offset of this lane's chunk within a 32-channel group of that row in swz[]
+template <int NTAPS>
+struct TapRows {
+  static constexpr int WORDS = (NTAPS + 3) / 4;
+  uint32_t rows[WORDS], swz[WORDS];
+  __device__ __forceinline__ uint32_t row(int tap) const { return (rows[tap >> 2] >> ((tap & 3) * 8)) & 0xffu; }
+  __device__ __forceinline__ uint32_t chunk(int tap) const { return (swz[tap >> 2] >> ((tap & 3) * 8)) & 0xffu; }
+};
+template <bool HEX, int NTAPS>
+__device__ __forceinline__ void wave_tap_rows(TapRows<NTAPS>& t, int row, int rows, int H, int Wd, int lane) {
+  const bool row_ok = row < rows;
+  const int cy = row / Wd, cx = row - cy * Wd;
+#pragma unroll
+  for (int w = 0; w < TapRows<NTAPS>::WORDS; ++w) { t.rows[w] = 0u; t.swz[w] = 0u; }
+#pragma unroll
+  for (int tap = 0; tap < NTAPS; ++tap) {
+    const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
+    const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
+    const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
+    const int r = on ? row + dy * Wd + dx : rows;       // (row index `rows`: every buffer's row of zeros)
+    t.rows[tap >> 2] |= (uint32_t)r << ((tap & 3) * 8);
+    t.swz[tap >> 2] |= (uint32_t)(((lane >> 4) ^ ((r >> 2) & 3)) << 4) << ((tap & 3) * 8);
+  }
+}
+
 template <int NTAPS, int KGT, int RT = 2>
-__device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restrict__ net, const int (&srow)[RT][NTAPS],
-                                          int off0, int cs0, int ps0, int kq, __amdgpu_buffer_rsrc_t wrs, int& wv,
-                                          u32x4 (&bq)[WAVE_AHEAD + 1][3], unsigned long long* tkn = nullptr,
-                                          unsigned long long* tsn = nullptr) {
+__device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const TapRows<NTAPS> (&srow)[RT], uint32_t src, uint32_t cs4,
+                                          __amdgpu_buffer_rsrc_t wrs, int& wv, u32x4 (&bq)[WAVE_AHEAD + 1][3],
+                                          unsigned long long* tkn = nullptr, unsigned long long* tsn = nullptr) {
   constexpr int STEPS = NTAPS * KGT;
   constexpr int AHEAD = WAVE_AHEAD;
   static_assert(STEPS >= AHEAD, "the prologue is always AHEAD steps");
   u32x4 a[2][RT][3];
-  auto load_a = [&](int st, u32x4 (&dst)[RT][3]) {
-    const int tap = st / KGT, kg = st - tap * KGT;
+  // a tap's operand address: source buffer + row x row stride + this lane's chunk (LDS byte address); two taps' worth are
+  // alive at a time
+  uint32_t ad[2][RT];
+  auto address = [&](int tap) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int r = srow[rt][tap];
-      const int a0 = off0 + (int)__umul24((unsigned)r, (unsigned)cs0) + (((kg * 4 + kq) ^ ((r >> 2) & 3)) << 2);
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece) {
-#ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
-        dst[rt][piece] = u32x4{(uint32_t)(a0 & 0), (uint32_t)(piece & 0), 0u, 0u};
-#else
-        dst[rt][piece] = *reinterpret_cast<const u32x4*>(net + a0 + piece * ps0);
-#endif
-      }
-    }
+    for (int rt = 0; rt < RT; ++rt) ad[tap & 1][rt] = __umul24(srow[rt].row(tap), cs4) + srow[rt].chunk(tap) + src;
   };
-  load_a(0, a[0]);
+  auto read = [&](int st, int rt, int piece) -> u32x4 {
+    const int tap = st / KGT, kg = st - tap * KGT;
+#ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
+    return u32x4{(uint32_t)(ad[tap & 1][rt] & 0), (uint32_t)(piece & 0), 0u, 0u};
+#else
+    return *reinterpret_cast<lds_u32x4>(ad[tap & 1][rt] + (uint32_t)((kg * GROUP_FLOATS + piece * PIECE_FLOATS) * 4));
+#endif
+  };
+  address(0);
+#pragma unroll
+  for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[0][rt][piece] = read(0, rt, piece);
+  if (STEPS > 1 && 1 / KGT != 0) address(1 / KGT);
 #ifdef NZ_PERSIST_HEADSTAMP   // diagnostic: how long a layer waits for its first operands (slot 3; perturbs the pipeline)
   if (tkn) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -865,39 +904,68 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const float* __restr
     *tsn = now;
   }
 #endif
+#if NZ_PERSIST_SPREAD
+  if constexpr (RT == 2) {
+    // A step as six SLOTS, each one pair of MFMAs (row tile 0, row tile 1; step16's term order) with loads in its shadow
+    // (an MFMA's gap hides eight cycles of other vector issue, no more): slots 0..2 the next step's operand reads in the
+    // order the next step's pairs want them (pieces 1, 2, 0: every read has a whole step to arrive), slot 3 the weights of
+    // AHEAD steps on, slot 4 the address of the tap after next.  Scheduling barriers between the slots: left to itself
+    // the scheduler put the reads behind the step's MFMAs (their latency at the head of every step); given load slots
+    // only, it ran each row tile's six MFMAs as one dependent chain.
 #pragma unroll
-  for (int st = 0; st < STEPS; ++st) {
-    if (st + 1 < STEPS) load_a(st + 1, a[(st + 1) & 1]);
-    if (st + AHEAD < STEPS) wave_weights_step(bq[(st + AHEAD) % (AHEAD + 1)], wrs, wv);
-#ifdef NZ_ABL_PERSIST_EARLYLDS
-    // experiment (not kept): force the next step's operand reads out BEFORE this step's MFMAs -- the pass alone 86.7 k
-    // ticks against 81.9 k, the round 775 against 970 games/s (longer live ranges, 54 spilled registers)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#if NZ_PERSIST_PAIRED
-    if constexpr (RT == 2) {
-      // The step's loads go out FIRST and its twelve MFMAs follow as six pairs (row tile 0, row tile 1) in step16's term
-      // order: left to itself the scheduler put the operand reads of step st + 1 behind the MFMAs of step st (their
-      // latency then sits at the head of every step: a third of the pass), and told to put them first it ran each row
-      // tile's six dependent MFMAs as one chain (every one waits for the one before it).
-      __builtin_amdgcn_sched_barrier(0);
+    for (int st = 0; st < STEPS; ++st) {
+      const bool more = st + 1 < STEPS;
       const u32x4 (&b)[3] = bq[st % (AHEAD + 1)];
       const u32x4 (&a0)[3] = a[st & 1][0];
       const u32x4 (&a1)[3] = a[st & 1][1];
+      u32x4 (&n0)[3] = a[(st + 1) & 1][0];
+      u32x4 (&n1)[3] = a[(st + 1) & 1][1];
+      u32x4 (&nb)[3] = bq[(st + AHEAD) % (AHEAD + 1)];
 #define NZ_PAIR(B, A)                         \
   acc[0] = wide_mfma(b[B], a0[A], acc[0]);    \
-  acc[1] = wide_mfma(b[B], a1[A], acc[1]);    \
-  __builtin_amdgcn_sched_barrier(0);
-      NZ_PAIR(1, 1) NZ_PAIR(0, 2) NZ_PAIR(2, 0) NZ_PAIR(0, 1) NZ_PAIR(1, 0) NZ_PAIR(0, 0)
+  acc[1] = wide_mfma(b[B], a1[A], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(1, 1)
+      if (more) { n0[1] = read(st + 1, 0, 1); n1[1] = read(st + 1, 1, 1); }
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(0, 2)
+      if (more) { n0[2] = read(st + 1, 0, 2); n1[2] = read(st + 1, 1, 2); }
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(2, 0)
+      if (more) { n0[0] = read(st + 1, 0, 0); n1[0] = read(st + 1, 1, 0); }
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(0, 1)
+      if (st + AHEAD < STEPS) wave_weights_step(nb, wrs, wv);
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(1, 0)
+      if (st + 2 < STEPS && (st + 2) / KGT != (st + 1) / KGT) address((st + 2) / KGT);
+      __builtin_amdgcn_sched_barrier(0);
+      NZ_PAIR(0, 0)
+      __builtin_amdgcn_sched_barrier(0);
 #undef NZ_PAIR
-    } else
-#endif
-    {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
-      __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
     }
+    return;
   }
+#endif
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) {
+    if (st + 1 < STEPS) {
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) a[(st + 1) & 1][rt][piece] = read(st + 1, rt, piece);
+    }
+    if (st + AHEAD < STEPS) wave_weights_step(bq[(st + AHEAD) % (AHEAD + 1)], wrs, wv);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) step16(acc[rt], a[st & 1][rt], bq[st % (AHEAD + 1)]);
+    if (st + 2 < STEPS && (st + 2) / KGT != (st + 1) / KGT) address((st + 2) / KGT);
+    __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
+  }
+}
+
+// float offset of (row, channel c0 = 16 ct + 4 (lane >> 4)) within a pieces buffer's row, piece 0
+__device__ __forceinline__ int pieces_chunk(int ct, int lane, int row) {
+  return (ct >> 1) * GROUP_FLOATS + (((((ct & 1) << 1) | (lane >> 5)) ^ ((row >> 2) & 3)) << 2) + ((lane >> 4) & 1) * 2;
 }
 
 // residual, activation, split into pieces (or float32 rows), store: fused16_net_kernel's epilogue for one tile
@@ -908,14 +976,14 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
 #ifdef NZ_ABL_PERSIST_NOEPI   // timing experiment: no epilogue (results wrong)
   if (acc[0] != 12345.678f) return;
 #endif
-  const int chunk = (((c0 >> 3) ^ ((orow >> 2) & 3)) << 2) + ((c0 & 7) >> 1);
+  const int chunk = pieces_chunk(ct, lane, orow);
   float v[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] = acc[r];
   if (op.offr >= 0) {
     const float* rp = net + op.offr + orow * op.csr + chunk;
-    const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + op.psr),
-                q2 = *reinterpret_cast<const uint2*>(rp + 2 * op.psr);
+    const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + PIECE_FLOATS),
+                q2 = *reinterpret_cast<const uint2*>(rp + 2 * PIECE_FLOATS);
     auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
     auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
     v[0] += (lo(q0.x) + lo(q1.x)) + lo(q2.x);
@@ -947,7 +1015,7 @@ __device__ __forceinline__ void wave_epilogue(const f32x4& acc, float* __restric
     float* dp = net + op.offd + orow * op.csd + chunk;
 #pragma unroll
     for (int piece = 0; piece < 3; ++piece)
-      *reinterpret_cast<uint2*>(dp + piece * op.psd) =
+      *reinterpret_cast<uint2*>(dp + piece * PIECE_FLOATS) =
           uint2{(uint32_t)h3[0][piece] | ((uint32_t)h3[1][piece] << 16), (uint32_t)h3[2][piece] | ((uint32_t)h3[3][piece] << 16)};
   }
 }
@@ -968,7 +1036,7 @@ __device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __r
   for (int rt = 0; rt < 2; ++rt) {
     orow[rt] = rt * 16 + (lane & 15);
     ok[rt] = orow[rt] < rows;
-    chunk[rt] = (((c0 >> 3) ^ ((orow[rt] >> 2) & 3)) << 2) + ((c0 & 7) >> 1);
+    chunk[rt] = pieces_chunk(ct, lane, orow[rt]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[rt][r] = acc[rt][r];
   }
@@ -977,8 +1045,8 @@ __device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __r
     for (int rt = 0; rt < 2; ++rt) {
       if (ok[rt]) {
         const float* rp = net + op.offr + orow[rt] * op.csr + chunk[rt];
-        const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + op.psr),
-                    q2 = *reinterpret_cast<const uint2*>(rp + 2 * op.psr);
+        const uint2 q0 = *reinterpret_cast<const uint2*>(rp), q1 = *reinterpret_cast<const uint2*>(rp + PIECE_FLOATS),
+                    q2 = *reinterpret_cast<const uint2*>(rp + 2 * PIECE_FLOATS);
         auto lo = [](uint32_t w) { return __builtin_bit_cast(float, w << 16); };
         auto hi = [](uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); };
         v[rt][0] += (lo(q0.x) + lo(q1.x)) + lo(q2.x);
@@ -1029,23 +1097,22 @@ __device__ __forceinline__ void wave_epilogue2(const f32x4 (&acc)[2], float* __r
     if (ok[rt]) {
       float* dp = net + op.offd + orow[rt] * op.csd + chunk[rt];
 #pragma unroll
-      for (int piece = 0; piece < 3; ++piece) *reinterpret_cast<uint2*>(dp + piece * op.psd) = q[rt][piece];
+      for (int piece = 0; piece < 3; ++piece) *reinterpret_cast<uint2*>(dp + piece * PIECE_FLOATS) = q[rt][piece];
     }
   }
 }
 
 template <int NTAPS, int KGT, int RT = 2>
 __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* __restrict__ net, const Fused16Op& op,
-                                                 const int (&srow)[RT][NTAPS], int ct, int lane, u32x4 (&bq)[WAVE_AHEAD + 1][3],
-                                                 int& wv, unsigned long long* tkn = nullptr, unsigned long long* tsn = nullptr) {
+                                                 const TapRows<NTAPS> (&srow)[RT], int ct, int lane,
+                                                 u32x4 (&bq)[WAVE_AHEAD + 1][3], int& wv, unsigned long long* tkn = nullptr,
+                                                 unsigned long long* tsn = nullptr) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // (an opaque k-quarter: the operand addresses of every step of every variant are loop-invariant arithmetic, and hoisted
-  // out of the layer loop they are 180 live registers)
-  int kq = lane >> 4;
-  asm volatile("" : "+v"(kq));
+  const uint32_t src = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) float*)(net + op.off0);
+  const uint32_t cs4 = (uint32_t)op.cs0 * 4u;
   const __amdgpu_buffer_rsrc_t wrs = wave_weights_rsrc(op.w + (size_t)ct * op.w_chunks * 4, op.w_chunks);
-  wave_conv<NTAPS, KGT, RT>(acc, net, srow, op.off0, op.cs0, op.ps0, kq, wrs, wv, bq, tkn, tsn);
+  wave_conv<NTAPS, KGT, RT>(acc, srow, src, cs4, wrs, wv, bq, tkn, tsn);
 }
 
 // The two wavefronts of a game meet (the leader runs the tree and half of every layer, the helper the other half): each
@@ -1079,20 +1146,9 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
   unsigned long long tsn = __builtin_amdgcn_s_memtime();
 #endif
   constexpr int ntaps = HEX ? 7 : 9;
-  int srow[2][ntaps];
+  TapRows<ntaps> srow[2];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int row = rt * 16 + (lane & 15);
-    const bool row_ok = row < rows;
-    const int cy = row / Wd, cx = row - cy * Wd;
-#pragma unroll
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
-      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
-      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
-      srow[rt][tap] = on ? row + dy * Wd + dx : rows;       // (row index `rows`: every buffer's row of zeros)
-    }
-  }
+  for (int rt = 0; rt < 2; ++rt) wave_tap_rows<HEX, ntaps>(srow[rt], rt * 16 + (lane & 15), rows, H, Wd, lane);
   typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
   constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
   static_assert(OP_DWORDS <= 64, "one dword per lane");
@@ -1170,9 +1226,12 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
     }
     if (odd) {
       const int ct = op.ntiles - 1;
-      int srow1[1][ntaps];
+      TapRows<ntaps> srow1[1];
 #pragma unroll
-      for (int tap = 0; tap < ntaps; ++tap) srow1[0][tap] = half ? srow[1][tap] : srow[0][tap];
+      for (int w = 0; w < TapRows<ntaps>::WORDS; ++w) {
+        srow1[0].rows[w] = half ? srow[1].rows[w] : srow[0].rows[w];
+        srow1[0].swz[w] = half ? srow[1].swz[w] : srow[0].swz[w];
+      }
       f32x4 acc[1];
       WSTAMP(4);
 #if !NZ_PERSIST_XOP
@@ -1212,19 +1271,8 @@ __device__ __forceinline__ void quad_network(const Fused16Program* __restrict__ 
                                              int H, int Wd, int lane, int quad, int* flags, int& seq) {
   constexpr int ntaps = HEX ? 7 : 9;
   const int rt = quad & 1, half = quad >> 1;
-  int srow[1][ntaps];
-  {
-    const int row = rt * 16 + (lane & 15);
-    const bool row_ok = row < rows;
-    const int cy = row / Wd, cx = row - cy * Wd;
-#pragma unroll
-    for (int tap = 0; tap < ntaps; ++tap) {
-      const int dy = HEX ? (tap < 3 ? tap - 1 : ((tap - 3) & 1) - 1 + (cx & 1)) : tap / 3 - 1;
-      const int dx = HEX ? (tap < 3 ? 0 : (tap < 5 ? -1 : 1)) : tap % 3 - 1;
-      const bool on = row_ok && (unsigned)(cy + dy) < (unsigned)H && (unsigned)(cx + dx) < (unsigned)Wd;
-      srow[0][tap] = on ? row + dy * Wd + dx : rows;
-    }
-  }
+  TapRows<ntaps> srow[1];
+  wave_tap_rows<HEX, ntaps>(srow[0], rt * 16 + (lane & 15), rows, H, Wd, lane);
   typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
   constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
   const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
@@ -1280,7 +1328,7 @@ __device__ __forceinline__ int legal_list_wave(const ScsRules& R, const ScsState
 // This wavefront's half (`half` = 0 leader, 1 helper) of turning the staged float32 planes into the input pieces (every
 // row of the input region, its row of zeros included) ...
 __device__ __forceinline__ void split_planes_half(float* __restrict__ net, const PersistArgs& q, int hw, int in_off, int in_cs,
-                                                  int in_ps, int lane, int half) {
+                                                  int lane, int half) {
   const float* const stage = net + q.stage_off;
   const int chunks = q.inp >> 3;
   for (int i = lane + 64 * half; i < (hw + 1) * chunks; i += 128) {
@@ -1296,10 +1344,10 @@ __device__ __forceinline__ void split_planes_half(float* __restrict__ net, const
       }
       wide_split8(lo4, hi4, q0, q1, q2);
     }
-    float* d = net + in_off + r * in_cs + ((c8 ^ ((r >> 2) & 3)) << 2);
+    float* d = net + in_off + r * in_cs + (c8 >> 2) * GROUP_FLOATS + (((c8 & 3) ^ ((r >> 2) & 3)) << 2);
     *reinterpret_cast<u32x4*>(d) = q0;
-    *reinterpret_cast<u32x4*>(d + in_ps) = q1;
-    *reinterpret_cast<u32x4*>(d + 2 * in_ps) = q2;
+    *reinterpret_cast<u32x4*>(d + PIECE_FLOATS) = q1;
+    *reinterpret_cast<u32x4*>(d + 2 * PIECE_FLOATS) = q2;
   }
 }
 // ... and of zeroing the staging space again (it lies over the trunk buffers: their rows of zeros, channels no layer writes)
@@ -1341,7 +1389,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
 #define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops), planes = PHDR(planes);
-  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs), in_ps = PHDR(in_ps);
+  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs);
   const int pol_off = PHDR(pol_off), pp = PHDR(pol_cs), val_off = PHDR(val_off), vp = PHDR(val_cs);
 #undef PHDR
   scs_sync<false>();
@@ -1455,6 +1503,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       bool hit = false;
       if (p.c_bits > 0) {
         state_hash_wave(sc, lane, key_hi, key_lo);
+        key_hi = uniform64(key_hi); key_lo = uniform64(key_lo);         // (the same on every lane: scalar registers)
         entry = (size_t)(key_lo & ((1ull << p.c_bits) - 1));
         unsigned long long* const id = reinterpret_cast<unsigned long long*>(p.c_id + 2 * entry);
         const unsigned long long id0 = __hip_atomic_load(id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1518,7 +1567,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         }
       }
       if (!hit) {
-      split_planes_half(net, q, hw, in_off, in_cs, in_ps, lane, 0);
+      split_planes_half(net, q, hw, in_off, in_cs, lane, 0);
       scs_sync<false>();
       pair_sync(flags, 0, seq, lane);             // (both halves of the pieces are made: the staging space can go)
       zero_stage_half(net, q, lane, 0);
@@ -1725,7 +1774,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
   const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
 #define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
-  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs), in_ps = PHDR(in_ps);
+  const int in_off = PHDR(in_off), in_cs = PHDR(in_cs);
 #undef PHDR
   const ScsState& sc = *reinterpret_cast<const ScsState*>(wb + PERSIST_STATE_BYTES);
   uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
@@ -1747,7 +1796,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
     pair_sync(flags, 1, seq, lane);
     const int job = flags[5], base = flags[7];
     if (job == 0 || k > p.maxc || base + k > p.half_cap) continue;     // (a hit, or the leader is raising the overflow flag)
-    split_planes_half(net, q, hw, in_off, in_cs, in_ps, lane, 1);
+    split_planes_half(net, q, hw, in_off, in_cs, lane, 1);
     scs_sync<false>();
     pair_sync(flags, 1, seq, lane);
     zero_stage_half(net, q, lane, 1);
