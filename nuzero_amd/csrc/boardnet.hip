@@ -1765,13 +1765,21 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
   const Place trunk[4] = {in_pl, {off_t, cs_w, ps_w}, {off_t + (int)act, cs_w, ps_w}, {off_t + 2 * (int)act, cs_w, ps_w}};
   const int t_out = h->ops[n_trunk].src0;
   if (t_out < 1 || t_out > 3) return no("internal: trunk output buffer");
+  // The two heads are independent chains behind the trunk (blocks.py:56-66,144-153): the pair's leader runs the policy
+  // head's two layers, its helper the value head's four, side by side with no meeting in between -- if the policy head's
+  // hidden buffer (which then cannot share a trunk buffer with the value head's) fits behind the logits' and the value
+  // plane's rows in the input pieces' space, free since the first layer.
+  const size_t hid_floats = pieces_floats(h->buffer_channels[4]);
+  const size_t off_hid = (pol_floats + val_floats + 3) / 4 * 4;
+  const bool solo = off_hid + hid_floats <= pieces_floats(h->inp) && getenv("NZ_SCS_PERSIST_NO_SOLO") == nullptr;
+  const int cs_hid = cs_of(h->buffer_channels[4]);
   int free_ids[2], nf = 0;
   for (int b = 1; b <= 3; ++b)
     if (b != t_out) free_ids[nf++] = b;
   const Place pol_pl{pg.pol_off, pol_cs, 0}, val_pl{pg.val_off, val_cs, 0};
   auto place_of = [&](int id, bool last_value) -> Place {
     if (id >= 0 && id <= 3) return trunk[id];
-    if (id == 4) return trunk[free_ids[0]];
+    if (id == 4) return solo ? Place{off_i + (int)off_hid, cs_hid, 16} : trunk[free_ids[0]];
     if (id == 5) return pol_pl;
     if (last_value) return val_pl;
     return trunk[free_ids[id == 6 ? 0 : 1]];
@@ -1796,6 +1804,8 @@ bool nz::boardnet_wave_program(nz_boardnet* h, nz::WaveNet* out, std::string* wh
     if (f.kg0 * 48 > f.cs0) return no("internal: K groups beyond the source rows");
     if (dst.ps != 0 && (f.ntiles + 1) / 2 * 48 > dst.cs) return no("internal: output tiles beyond the destination rows");
   }
+  pg.solo_at = solo ? n_trunk : n_ops; pg.solo_pol = 2;
+  pg.solo_zero_off = off_i + (int)off_hid + rows * cs_hid; pg.solo_zero_len = solo ? cs_hid : 0;
   Fused16Program* dev = nullptr;
   if (hipMalloc((void**)&dev, sizeof(pg)) != hipSuccess) return no("device allocation failed");
   if (hipMemcpy(dev, &pg, sizeof(pg), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return no("upload failed"); }

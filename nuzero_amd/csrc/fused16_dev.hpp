@@ -56,6 +56,10 @@ struct Fused16Program {
   int32_t wbuf_off[2];
   int32_t in_off, in_cs, in_ps, pol_off, pol_cs, val_off, val_cs, pad;
   int32_t zero_at_op, n_zero, zero_off[6], zero_len;   // rows of zeros to (re)make before that layer: buffers that take over a weight buffer's space
+  // the per-wavefront-pair program (boardnet_wave_program) only: the layers from solo_at on are two independent chains
+  // (the policy head's solo_pol layers, then the value head's) that the pair's two wavefronts run side by side; the first
+  // chain's hidden buffer has its row of zeros at float offset solo_zero_off (solo_zero_len floats), remade every pass
+  int32_t solo_at, solo_pol, solo_zero_off, solo_zero_len;
   Fused16Op ops[FUSED_MAX_OPS];
 };
 // one K step (32 channels of one tap): the six piece products, small terms first (net_dev.hpp pair_mfma)

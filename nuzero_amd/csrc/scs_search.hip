@@ -797,13 +797,13 @@ __device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, 
 // straight-line code.  Activations (the MFMA's second operand) come from LDS, this lane's operand row per tap in srow,
 // read one step ahead of the MFMAs that use them; the weights (first operand) straight from the packed L2 stream, their
 // loads running AHEAD steps in front (an L2 round trip is several steps long).
-#ifndef NZ_PERSIST_XOP
-#define NZ_PERSIST_XOP 0          // 1: a job's first weights are fetched under the epilogue of the job before it
-#endif
 #ifndef NZ_PERSIST_AHEAD
 #define NZ_PERSIST_AHEAD 2
 #endif
 constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
+#ifndef NZ_PERSIST_KPRIO
+#define NZ_PERSIST_KPRIO 0        // > 0: the K loops run at this wavefront priority
+#endif
 #ifndef NZ_PERSIST_SPREAD
 #define NZ_PERSIST_SPREAD 1       // 1: a K step's loads placed one per MFMA gap (wave_conv)
 #endif
@@ -811,7 +811,12 @@ constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
 // (buffer loads: a wave-uniform descriptor of the column tile's stream, ONE vector register with this lane's byte offset,
 // the step's offset as a scalar -- plain global loads keep a 64-bit address pair alive per load in flight, forty registers)
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wave_weights_rsrc(const uint32_t* wg, int chunks16) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wg), (short)0, chunks16 * 16, 0x00020000);
+  // (pinned to scalar registers: taken for lane-dependent, the descriptor makes every load of the stream a loop over
+  // the lanes' values -- seen once, a fifth of the round)
+  const uint64_t a = (uint64_t)(uintptr_t)wg;
+  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint32_t*>((uintptr_t)u), (short)0,
+                                           __builtin_amdgcn_readfirstlane(chunks16 * 16), 0x00020000);
 }
 // one step's three pieces; the stream position is ONE running vector register (the step's 3 KB added after its loads, the
 // pieces as immediate offsets): a scalar offset per (step, piece) was forty scalar registers of constants held across
@@ -904,6 +909,9 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const TapRows<NTAPS>
     *tsn = now;
   }
 #endif
+#if NZ_PERSIST_KPRIO
+  __builtin_amdgcn_s_setprio(NZ_PERSIST_KPRIO);     // (matrix work before the SIMD's other wavefront's vector work)
+#endif
 #if NZ_PERSIST_SPREAD
   if constexpr (RT == 2) {
     // A step as six SLOTS, each one pair of MFMAs (row tile 0, row tile 1; step16's term order) with loads in its shadow
@@ -944,6 +952,9 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const TapRows<NTAPS>
       __builtin_amdgcn_sched_barrier(0);
 #undef NZ_PAIR
     }
+#if NZ_PERSIST_KPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     return;
   }
 #endif
@@ -961,6 +972,9 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const TapRows<NTAPS>
     if (st + 2 < STEPS && (st + 2) / KGT != (st + 1) / KGT) address((st + 2) / KGT);
     __builtin_amdgcn_sched_barrier(0);          // (the scheduler would hoist every later step's loads up here: spills)
   }
+#if NZ_PERSIST_KPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 // float offset of (row, channel c0 = 16 ct + 4 (lane >> 4)) within a pieces buffer's row, piece 0
@@ -1138,67 +1152,69 @@ __device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane
 #else
 #define WSTAMP(slot)
 #endif
+// The per-pass constants of wave_network: the program's header words it needs (read once per move by the caller).
+struct WaveNetArgs {
+  const Fused16Program* prog;
+  int n_ops, rows, H, Wd;
+  int solo_at, solo_pol, solo_zero_off, solo_zero_len;
+};
+// Every layer of the network for the position whose input pieces sit in the game's block.  Trunk layers: this wavefront
+// takes column tiles half, half + 2, ... of the layer's PAIRS of column tiles (both row tiles each), then row tile `half`
+// of an odd last column tile (whole it was the leader's alone and the helper waited), and the pair meets after every
+// layer.  Head layers (from solo_at on): the leader runs the policy head's chain, the helper the value head's, every tile
+// of every layer, with no meeting -- the CALLER holds the last one (the leader after its softmax, which needs the
+// logits only).
 template <bool HEX>
-__device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ prog, float* __restrict__ net, int n_ops, int rows,
-                                             int H, int Wd, int lane, int half, int* flags, int& seq,
+__device__ __forceinline__ void wave_network(const WaveNetArgs& wn, float* __restrict__ net, int lane, int half, int* flags, int& seq,
                                              unsigned long long* tkn = nullptr) {
 #ifdef NZ_PERSIST_STAMPS
   unsigned long long tsn = __builtin_amdgcn_s_memtime();
 #endif
   constexpr int ntaps = HEX ? 7 : 9;
+  const int n_ops = wn.n_ops, rows = wn.rows;
   TapRows<ntaps> srow[2];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) wave_tap_rows<HEX, ntaps>(srow[rt], rt * 16 + (lane & 15), rows, H, Wd, lane);
+  for (int rt = 0; rt < 2; ++rt) wave_tap_rows<HEX, ntaps>(srow[rt], rt * 16 + (lane & 15), rows, wn.H, wn.Wd, lane);
   typedef const __attribute__((address_space(1))) uint32_t* gptr1u;
   constexpr int OP_DWORDS = (int)(sizeof(Fused16Op) / 4);
   static_assert(OP_DWORDS <= 64, "one dword per lane");
-  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(prog->ops);
+  const gptr1u ops_words = (gptr1u)reinterpret_cast<const uint32_t*>(wn.prog->ops);
   auto unpack = [](uint32_t v, Fused16Op& op) {
     uint32_t words[OP_DWORDS];
 #pragma unroll
     for (int i = 0; i < OP_DWORDS; ++i) words[i] = __builtin_amdgcn_readlane(v, i);
     __builtin_memcpy(&op, words, sizeof(Fused16Op));
   };
+  // this wavefront's layers in order: the shared ones, then its own chain
+  const int solo_at = wn.solo_at < n_ops ? wn.solo_at : n_ops;
+  const int chain_first = half == 0 ? solo_at : solo_at + wn.solo_pol;
+  const int chain_len = solo_at < n_ops ? (half == 0 ? wn.solo_pol : n_ops - solo_at - wn.solo_pol) : 0;
+  const int n_mine = solo_at + chain_len;
+  auto layer_at = [&](int i) { return i < solo_at ? i : chain_first + (i - solo_at); };
   // A layer's descriptor stays in ONE vector register (a dword per lane, fetched a layer ahead) until the layer starts:
   // unpacked a layer early its fields were scalar registers the K loop had no room for (spilled to lanes and back).
-  uint32_t cur = lane < OP_DWORDS ? ops_words[lane] : 0u;
-  uint32_t nxt = (n_ops > 1 && lane < OP_DWORDS) ? ops_words[OP_DWORDS + lane] : 0u;
+  uint32_t cur = (n_mine > 0 && lane < OP_DWORDS) ? ops_words[layer_at(0) * OP_DWORDS + lane] : 0u;
+  uint32_t nxt = (n_mine > 1 && lane < OP_DWORDS) ? ops_words[layer_at(1) * OP_DWORDS + lane] : 0u;
   int wv = 0;
-  // This wavefront's jobs of a layer: column tiles half, half + 2, ... of the layer's PAIRS of column tiles (both row
-  // tiles each), then row tile `half` of an odd last column tile (whole it was the leader's alone and the helper waited).
   u32x4 bq[WAVE_AHEAD + 1][3];
   auto job_weights = [&](const Fused16Op& x, int ct) {
     wave_weights_prologue(bq, wave_weights_rsrc(x.w + (size_t)ct * x.w_chunks * 4, x.w_chunks), wv, lane);
   };
-  [[maybe_unused]] auto first_job = [&](const Fused16Op& x) { return half < (x.ntiles & ~1) ? half : x.ntiles - 1; };
-#if NZ_PERSIST_XOP
-  // A job's first weights are fetched while the job before it finishes (XOP 1: under its epilogue and the meeting, 2: under
-  // the meeting and the next layer's header only): an L2 round trip at the head of every layer otherwise.  (The meeting
-  // orders LDS only: a fence over global memory too would wait for these loads.)
-  {
-    Fused16Op first;
-    unpack(cur, first);
-    job_weights(first, first_job(first));
-  }
-#endif
-  for (int o = 0; o < n_ops; ++o) {
+  for (int i = 0; i < n_mine; ++i) {
     Fused16Op op;
     unpack(cur, op);
     cur = nxt;
-    if (o + 2 < n_ops && lane < OP_DWORDS) nxt = ops_words[(o + 2) * OP_DWORDS + lane];
-#if NZ_PERSIST_XOP
-    Fused16Op next;
-    unpack(cur, next);               // (only w, w_chunks, ntiles are read)
-#endif
+    if (i + 2 < n_mine && lane < OP_DWORDS) nxt = ops_words[layer_at(i + 2) * OP_DWORDS + lane];
     const int kgt = op.kg0;
-    const int pair_tiles = op.ntiles & ~1;
-    const bool odd = op.ntiles & 1;
-    for (int ct = half; ct < pair_tiles; ct += 2) {
+    const bool shared = i < solo_at;
+    if (i == solo_at && half == 0 && lane * 4 < wn.solo_zero_len)       // (the policy head's hidden buffer: its row of zeros)
+      *reinterpret_cast<f32x4*>(net + wn.solo_zero_off + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pair_tiles = shared ? op.ntiles & ~1 : op.ntiles;
+    const bool odd = shared && (op.ntiles & 1);
+    for (int ct = shared ? half : 0; ct < pair_tiles; ct += shared ? 2 : 1) {
       f32x4 acc[2];
       WSTAMP(4);                    // (the layer's header: descriptor words, addresses)
-#if !NZ_PERSIST_XOP
       job_weights(op, ct);
-#endif
 #ifdef NZ_PERSIST_STAMPS
       if (kgt == 1) wave_layer_kloop<ntaps, 1>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
       else if (kgt == 2) wave_layer_kloop<ntaps, 2>(acc, net, op, srow, ct, lane, bq, wv, tkn, &tsn);
@@ -1211,17 +1227,7 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
       else wave_layer_kloop<ntaps, 4>(acc, net, op, srow, ct, lane, bq, wv);
 #endif
       WSTAMP(0);
-#if NZ_PERSIST_XOP == 1
-      if (ct + 2 < pair_tiles) job_weights(op, ct + 2);
-      else if (odd) job_weights(op, op.ntiles - 1);
-      else if (o + 1 < n_ops) job_weights(next, first_job(next));
-#endif
       wave_epilogue2(acc, net, op, ct, lane, rows);
-#if NZ_PERSIST_XOP == 2
-      if (ct + 2 < pair_tiles) job_weights(op, ct + 2);
-      else if (odd) job_weights(op, op.ntiles - 1);
-      else if (o + 1 < n_ops) job_weights(next, first_job(next));
-#endif
       WSTAMP(1);
     }
     if (odd) {
@@ -1234,24 +1240,17 @@ __device__ __forceinline__ void wave_network(const Fused16Program* __restrict__ 
       }
       f32x4 acc[1];
       WSTAMP(4);
-#if !NZ_PERSIST_XOP
       job_weights(op, ct);
-#endif
       if (kgt == 1) wave_layer_kloop<ntaps, 1, 1>(acc, net, op, srow1, ct, lane, bq, wv);
       else if (kgt == 2) wave_layer_kloop<ntaps, 2, 1>(acc, net, op, srow1, ct, lane, bq, wv);
       else if (kgt == 3) wave_layer_kloop<ntaps, 3, 1>(acc, net, op, srow1, ct, lane, bq, wv);
       else wave_layer_kloop<ntaps, 4, 1>(acc, net, op, srow1, ct, lane, bq, wv);
       WSTAMP(0);
-#if NZ_PERSIST_XOP == 1
-      if (o + 1 < n_ops) job_weights(next, first_job(next));
-#endif
       wave_epilogue(acc[0], net, op, half, ct, lane, rows);
-#if NZ_PERSIST_XOP == 2
-      if (o + 1 < n_ops) job_weights(next, first_job(next));
-#endif
       WSTAMP(1);
     }
-    pair_sync(flags, half, seq, lane);     // the layer is whole before either half reads it (or overwrites its source)
+    if (shared) pair_sync(flags, half, seq, lane);     // the layer is whole before either half reads it (or overwrites its source)
+    else scs_sync<false>();                            // (this wavefront's own stores, then its own reads: LDS keeps their order)
     WSTAMP(2);
   }
 }
@@ -1391,6 +1390,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops), planes = PHDR(planes);
   const int in_off = PHDR(in_off), in_cs = PHDR(in_cs);
   const int pol_off = PHDR(pol_off), pp = PHDR(pol_cs), val_off = PHDR(val_off), vp = PHDR(val_cs);
+  const WaveNetArgs wna{q.prog, n_ops, hw, H, Wd, PHDR(solo_at), PHDR(solo_pol), PHDR(solo_zero_off), PHDR(solo_zero_len)};
 #undef PHDR
   scs_sync<false>();
   int n_sim = 0, n_exp = 0, n_hit = 0, n_miss = 0;      // (of this move: 32 bits are plenty, and half the registers)
@@ -1575,9 +1575,9 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       pair_sync(flags, 0, seq, lane);
       PSTAMP(3);                                // split, staging cleared (halves)
 #ifdef NZ_PERSIST_STAMPS
-      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq, tk + 10);
+      wave_network<HEX>(wna, net, lane, 0, flags, seq, tk + 10);
 #else
-      wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 0, flags, seq);
+      wave_network<HEX>(wna, net, lane, 0, flags, seq);
 #endif
       PSTAMP(4);                                // network
 
@@ -1616,6 +1616,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
         for (int w = 32; w; w >>= 1) ps += __shfl_xor(ps, w, 64);
         sum += ps;
       }
+      pair_sync(flags, 0, seq, lane);             // (the helper's value head is done)
       float sv = lane < hw ? net[val_off + lane * vp] : 0.f;
       for (int w = 32; w; w >>= 1) sv += __shfl_xor(sv, w, 64);
       value = tanhf(sv / (float)hw);
@@ -1775,6 +1776,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
 #define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
   const int in_off = PHDR(in_off), in_cs = PHDR(in_cs);
+  const WaveNetArgs wna{q.prog, n_ops, hw, H, Wd, PHDR(solo_at), PHDR(solo_pol), PHDR(solo_zero_off), PHDR(solo_zero_len)};
 #undef PHDR
   const ScsState& sc = *reinterpret_cast<const ScsState*>(wb + PERSIST_STATE_BYTES);
   uint32_t* const smask = reinterpret_cast<uint32_t*>(wb + 2 * PERSIST_STATE_BYTES);
@@ -1802,7 +1804,8 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
     zero_stage_half(net, q, lane, 1);
     scs_sync<false>();
     pair_sync(flags, 1, seq, lane);
-    wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, 1, flags, seq);
+    wave_network<HEX>(wna, net, lane, 1, flags, seq);
+    pair_sync(flags, 1, seq, lane);               // (the value plane is whole; the leader has done its softmax meanwhile)
   }
 }
 
@@ -1856,6 +1859,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
   const uint32_t hdr_v = lane < HDR_DWORDS ? ((gptr1u)reinterpret_cast<const uint32_t*>(q.prog))[lane] : 0u;
 #define PHDR(field) ((int)__builtin_amdgcn_readlane(hdr_v, (int)(offsetof(Fused16Program, field) / 4)))
   const int hw = PHDR(hw), H = PHDR(h), Wd = PHDR(wd), n_ops = PHDR(n_ops);
+  const WaveNetArgs wna{q.prog, n_ops, hw, H, Wd, PHDR(solo_at), PHDR(solo_pol), PHDR(solo_zero_off), PHDR(solo_zero_len)};
 #undef PHDR
   if (leader)
     for (int i = lane * 4; i < q.net_floats; i += 256) *reinterpret_cast<f32x4*>(net + i) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1867,7 +1871,10 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
   const int phase = (iters >> 24) - 1;
   const int active = (iters >> 16) & 0xff ? (iters >> 16) & 0xff : PERSIST_GAMES, n_it = iters & 0xffff;
   if (slot < active)
-    for (int it = 0; it < n_it; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq, tkn);
+    for (int it = 0; it < n_it; ++it) {
+      wave_network<HEX>(wna, net, lane, leader ? 0 : 1, flags, seq, tkn);
+      pair_sync(flags, leader ? 0 : 1, seq, lane);
+    }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   unsigned long long rep = t1 - t0;
   for (int k = 0; k < 5; ++k) if (phase == k) rep = tkn[k];
@@ -1877,7 +1884,10 @@ __global__ __launch_bounds__(PERSIST_THREADS) void netbench_kernel(PersistArgs q
 #else
   const int active = (iters >> 16) & 0xff ? (iters >> 16) & 0xff : PERSIST_GAMES, n_it = iters & 0xffff;
   if (slot < active)
-    for (int it = 0; it < n_it; ++it) wave_network<HEX>(q.prog, net, n_ops, hw, H, Wd, lane, leader ? 0 : 1, flags, seq);
+    for (int it = 0; it < n_it; ++it) {
+      wave_network<HEX>(wna, net, lane, leader ? 0 : 1, flags, seq);
+      pair_sync(flags, leader ? 0 : 1, seq, lane);
+    }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
   if (leader && lane == 0) out[blockIdx.x * PERSIST_GAMES + slot] = (t1 - t0) / (unsigned long long)n_it;
 #endif
