@@ -801,6 +801,9 @@ __device__ __forceinline__ uint64_t cache_check_word(uint64_t acc, float value, 
 #define NZ_PERSIST_AHEAD 2
 #endif
 constexpr int WAVE_AHEAD = NZ_PERSIST_AHEAD;
+#ifndef NZ_PERSIST_SYNC_DRAIN
+#define NZ_PERSIST_SYNC_DRAIN 0   // 1: a meeting waits for this wavefront's LDS stores before it posts its number
+#endif
 #ifndef NZ_PERSIST_KPRIO
 #define NZ_PERSIST_KPRIO 0        // > 0: the K loops run at this wavefront priority
 #endif
@@ -890,7 +893,7 @@ __device__ __forceinline__ void wave_conv(f32x4 (&acc)[RT], const TapRows<NTAPS>
   auto read = [&](int st, int rt, int piece) -> u32x4 {
     const int tap = st / KGT, kg = st - tap * KGT;
 #ifdef NZ_ABL_PERSIST_NOA    // timing experiment: no LDS operand reads (results wrong)
-    return u32x4{(uint32_t)(ad[tap & 1][rt] & 0), (uint32_t)(piece & 0), 0u, 0u};
+    return u32x4{(uint32_t)(ad[tap & 1][rt] & 0), (uint32_t)(piece & 0), (uint32_t)rt, 0u};   // (row tiles stay distinct chains)
 #else
     return *reinterpret_cast<lds_u32x4>(ad[tap & 1][rt] + (uint32_t)((kg * GROUP_FLOATS + piece * PIECE_FLOATS) * 4));
 #endif
@@ -1134,7 +1137,13 @@ __device__ __forceinline__ void wave_layer_kloop(f32x4 (&acc)[RT], const float* 
 // order, so the partner that sees the number sees the activations stored before it.
 __device__ __forceinline__ void pair_sync(int* flags, int me, int& seq, int lane) {
   ++seq;
+#if NZ_PERSIST_SYNC_DRAIN
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      // (LDS only: everything a pair shares is in LDS)
+#else
+  // (no wait for the stores: the LDS takes one wavefront's operations in the order they were issued, so the number
+  // lands behind the activations; the compiler is told not to move them)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#endif
   if (lane == 0) __hip_atomic_store(&flags[me], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef NZ_PERSIST_SYNC_SLEEP
 #define NZ_PERSIST_SYNC_SLEEP 0
