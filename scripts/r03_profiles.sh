@@ -24,10 +24,12 @@ python3 $R/scripts/pmc_summary.py $(ls /tmp/p_s2/*/*counter_collection.csv | hea
 cat $O/pmc_persist_kernel_sq.txt
 timeout -k 10 300 python3 $R/bench_scs.py --games 1024 --round-games 4096 > $O/scs_round4.log 2>&1 || exit 1
 timeout -k 10 300 python3 $R/bench_scs.py --games 1024 --cache 1048576 > $O/scs_cache.log 2>&1 || exit 1
-# the network of the persistent route alone, and its timing-only builds
+# the network of the persistent route alone: its phases (stamped build), without the heads' side-by-side chains, and its
+# timing-only builds
 ( echo "== product build"; timeout -k 10 120 python3 $R/scripts/persist_netbench.py
-  for v in pnoa pnob pnoab pnoepi pnone; do echo "== $v"; NZ_LIB_PATH=$R/scripts/ablate/lib_$v.so timeout -k 10 120 python3 $R/scripts/persist_netbench.py; done
-  echo "== four wavefronts per game (netbench4_kernel)"; NZ_NETBENCH_QUAD=1 timeout -k 10 120 python3 $R/scripts/persist_netbench.py ) 2>&1 | grep -v amdgpu.ids > $O/persist_netbench.txt
+  echo "== product build, heads layer by layer (NZ_SCS_PERSIST_NO_SOLO=1)"; NZ_SCS_PERSIST_NO_SOLO=1 timeout -k 10 120 python3 $R/scripts/persist_netbench.py
+  echo "== phases of a pass (-DNZ_PERSIST_STAMPS -DNZ_PERSIST_HEADSTAMP; the stamps cost ~10 %)"; NZ_NETBENCH_PHASES=1 NZ_LIB_PATH=$R/scripts/ablate/lib_phead.so timeout -k 10 200 python3 $R/scripts/persist_netbench.py
+  for v in pnoa pnob pnoab pnoepi pnone; do echo "== $v"; NZ_LIB_PATH=$R/scripts/ablate/lib_$v.so timeout -k 10 120 python3 $R/scripts/persist_netbench.py; done ) 2>&1 | grep -v amdgpu.ids > $O/persist_netbench.txt
 cat $O/persist_netbench.txt
 NZ_LIB_PATH=$R/scripts/ablate/lib_pstamps.so timeout -k 10 300 python3 $R/bench_scs.py --games 1024 > $O/scs_stamps.log 2>&1
 tail -1 $O/scs_1024.log | cut -c1-600
