@@ -140,3 +140,29 @@ def test_persistent_route_says_why_it_is_not_available():
     sp.play_native(net, [1, 2, 3, 4], max_moves=1)      # the default falls back to the wave-by-wave route
     assert sp.persistent() is False
     sp.close(); net.close()
+
+
+@pytest.mark.parametrize("arch", ["convnet", "resnet"])
+def test_heads_side_by_side_play_the_same_games_as_layer_by_layer(arch, monkeypatch):
+    """The persistent route runs the policy head on a game's leader wavefront and the value head on its helper, side by
+    side (boardnet_wave_program's solo chains); NZ_SCS_PERSIST_NO_SOLO keeps every head layer split between the two with
+    a meeting after each.  Same arithmetic either way: the same games, bit for bit."""
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    path = os.path.join(GOLDEN, "scs_configs", "mirrored_5x5.yml")
+    cfg = ScsGameConfig(path)
+    G = 8
+    search = a1_search(32, number_of_softmax_moves=3, epsilon_softmax_exploration=0.1, root_exploration_fraction=0.25,
+                       root_dist_alpha=0.3)
+    seeds = list(range(700, 700 + G))
+    out = []
+    for no_solo in (False, True):
+        if no_solo:
+            monkeypatch.setenv("NZ_SCS_PERSIST_NO_SOLO", "1")      # read when a net's per-wavefront program is built
+        net, _ = _net(cfg, arch, 32, 2, seed=5, gain=2.0, max_batch=G)
+        sp = ScsSelfPlay(cfg, search, G)
+        sp.persistent(1)
+        out.append(sp.play_native(net, seeds, max_moves=12))
+        assert sp.persistent() is True
+        sp.close(); net.close()
+    _same_games(out[0], out[1], [(g, g) for g in range(G)], arch)
+    assert out[0]["expansions"] == out[1]["expansions"] and out[0]["simulations"] == out[1]["simulations"]
