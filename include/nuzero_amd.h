@@ -476,6 +476,10 @@ nz_status nz_scs_search_persist_ticks(nz_scs_search* h, int64_t* out13_host);
 /* Diagnostic: the persistent route's network alone -- `blocks` workgroups of four (leader, helper) wavefront pairs each
  * run `iters` passes on an all-zero input; ticks_host[blocks * 4] = shader ticks per pass. */
 nz_status nz_scs_netbench(nz_boardnet* net, int32_t blocks, int32_t iters, uint64_t* ticks_host);
+/* Diagnostic (-DNZ_WIDE_STAMPS builds of the library only, NZ_ERR_STATE otherwise): phase ticks of conv_wide_kernel's K
+ * steps summed over its launches so far -- [0] loads issued, [1] first fragments read, [2] MFMAs + staging, [3] barrier,
+ * [4] loop overhead, [5] K steps, [6] launches, [7] 0.  No reference counterpart. */
+nz_status nz_boardnet_wide_stamps(uint64_t* out8);
 nz_status nz_scs_search_record(nz_scs_search* h, const int32_t* games_host, int32_t n, int32_t capacity);
 nz_status nz_scs_search_record_read(nz_scs_search* h, int32_t slot, int32_t* count, uint64_t* digests_host,
                                     float* probs_host, float* values_host);

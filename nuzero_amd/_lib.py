@@ -138,6 +138,7 @@ SIGNATURES = {
     "nz_scs_search_persist_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),
     "nz_scs_search_persist_profile": (c_int32, [c_void_p, c_int32, POINTER(ctypes.c_double)]),
     "nz_scs_netbench": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "nz_boardnet_wide_stamps": (c_int32, [c_void_p]),
     "nz_scs_search_record": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
     "nz_scs_search_record_read": (c_int32, [c_void_p, c_int32, POINTER(c_int32), c_void_p, c_void_p, c_void_p]),
     "nz_scs_search_phase_ticks": (c_int32, [c_void_p, POINTER(c_int64)]),

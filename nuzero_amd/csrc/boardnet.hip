@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/nuzero_amd.h"
@@ -215,9 +216,35 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvArgs p) {
 // positions x 64 channels = 32 accumulator tiles and issues 192 MFMAs per step from 36 LDS fragment reads.
 // Weights are the MFMA's A operand, so a lane ends up with four consecutive channels of one position:
 // the epilogue is one 16-byte store (and residual load) per accumulator tile.
+#ifndef NZ_WIDE_INTERLEAVE
+#define NZ_WIDE_INTERLEAVE 0      // 1: the four column tiles' MFMA chains term by term (measured: no difference)
+#endif
+#ifdef NZ_ABLATE_WIDE_MFMA        // timing experiment: no matrix instructions (results wrong)
+#define WIDE_MFMA(w, x, c) f32x4{(c)[0] + __builtin_bit_cast(float, (w)[0] & (x)[0]), (c)[1], (c)[2], (c)[3]}
+#else
+#define WIDE_MFMA(w, x, c) wide_mfma(w, x, c)
+#endif
+#ifndef NZ_WIDE_OVERLAP
+#define NZ_WIDE_OVERLAP 2         // 2: the next step's staging in the gaps of this step's MFMAs, operands fetched two steps ahead
+#endif
+#ifndef NZ_WIDE_XCD
+#define NZ_WIDE_XCD 1             // workgroups that share an XCD take consecutive tiles
+#endif
+#ifndef NZ_WIDE_KQ_OUTER
+#define NZ_WIDE_KQ_OUTER 1        // K loop: channel groups outside, taps inside
+#endif
+#if NZ_WIDE_OVERLAP == 2 && !NZ_WIDE_KQ_OUTER
+#error "the two-steps-ahead loop moves its cursor in channel-group order"
+#endif
 constexpr int WIDE_GROUPS = 16;          // position groups (of 16) per workgroup tile
 constexpr int WIDE_NT = 8;               // 16-channel column tiles per workgroup tile
 
+#ifdef NZ_WIDE_STAMPS      // diagnostic build: where a K step of conv_wide_kernel goes (workgroup 0's wavefront 0; nz_boardnet_wide_stamps)
+__device__ unsigned long long g_wide_stamps[8];
+#define WIDE_STAMP(slot) { if (stamping) { const unsigned long long now = __builtin_amdgcn_s_memtime(); wtk[slot] += now - wts; wts = now; } }
+#else
+#define WIDE_STAMP(slot)
+#endif
 template <bool HEX>
 __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
   __shared__ u32x4 sA[2][3][WIDE_GROUPS * 16][4];      // [buffer][piece][position][16-byte slot, swizzled]
@@ -226,9 +253,21 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_pos = p.n_dev ? *p.n_dev : p.n_host;
   const int n_groups = (n_pos + 15) >> 4;
-  const int cell = blockIdx.x % p.hw, gbase = (blockIdx.x / p.hw) * WIDE_GROUPS;
+  // Which tile: the dispatcher deals consecutive workgroups round the eight XCDs (each with its own L2), so the ids that
+  // share an XCD are given CONSECUTIVE tiles -- one 128-channel tile's weights and neighbouring cells of one position
+  // block: with the K loop below running a 32-channel group's taps back to back, a cell's slice fetched for one tap is
+  // in that L2 when the neighbours' workgroups want it for theirs (25 cells x 9 taps = 45 cells' slices instead of 225).
+  int bid = blockIdx.x + gridDim.x * blockIdx.y;
+#if NZ_WIDE_XCD
+  {
+    const int nwg = gridDim.x * gridDim.y, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+#endif
+  const int ct = bid / (int)gridDim.x;                 // tile of 128 output channels
+  const int bx = bid - ct * (int)gridDim.x;
+  const int cell = bx % p.hw, gbase = (bx / p.hw) * WIDE_GROUPS;
   if (gbase >= n_groups) return;                       // uniform per workgroup
-  const int ct = blockIdx.y;                           // tile of 128 output channels
   const int kq0 = p.c0 >> 5, kq1 = p.src1 ? (p.c1 >> 5) : 0, kqt = kq0 + kq1;      // 32-channel groups
 
   constexpr int ntaps = HEX ? 7 : 9;
@@ -254,13 +293,32 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     my_live[j] = group < n_groups;
     my_row[j] = (group * p.hw + cell) * 16 + (ppos & 15);
   }
+#if NZ_WIDE_OVERLAP == 2
+  // byte offsets of this thread's eight row slices within either source (a dead row -- a position group past the batch --
+  // reads the tile's first group instead of branching round its load: its outputs are never stored, and a row of the MFMA
+  // only sees its own operand row)
+  uint32_t rowoff0[8], rowoff1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ppos = (tid >> 3) + 32 * j;
+    const int row = ((my_live[j] ? gbase + (ppos >> 4) : gbase) * p.hw + cell) * 16 + (ppos & 15);
+    rowoff0[j] = ((uint32_t)row * (uint32_t)p.s0 + (uint32_t)my_chunk * 4u) * 4u;
+    rowoff1[j] = ((uint32_t)row * (uint32_t)p.s1 + (uint32_t)my_chunk * 4u) * 4u;
+  }
+#endif
   const u32x4* wtile = reinterpret_cast<const u32x4*>(p.ws) + (size_t)ct * (ntaps + 1) * kqt * (3 * WIDE_NT * 64);
   uint32_t taps_left = vmask;
-  int tap = __ffs(taps_left) - 1, kq = 0;              // the centre tap is always on the board
+  int tap = __ffs(taps_left) - 1, kq = 0, fs = 0;      // the cursor: step fs = (kq, tap); the centre tap is always on the board
   taps_left &= taps_left - 1;
-  f32x4 ra[8];
-  u32x4 rb[6];
-  auto fetch = [&]() {                                 // global -> registers for the cursor's step, then advance
+  // fetched operands wait in registers: two sets, so that a step's loads are issued TWO steps ahead (with one wavefront per
+  // SIMD a load that is waited for is time nothing else fills: a quarter of the L2 requests miss)
+  f32x4 ra2[2][8];
+  u32x4 rb2[2][6];
+  typedef std::integral_constant<int, 0> Set0;
+  typedef std::integral_constant<int, 1> Set1;
+  auto fetch = [&](auto set) {                         // global -> registers for the cursor's step, then advance
+    f32x4 (&ra)[8] = ra2[decltype(set)::value];
+    u32x4 (&rb)[6] = rb2[decltype(set)::value];
     const int shift = (tap_dy(tap) * p.wd + tap_dx(tap)) * 16;
     const bool second = kq >= kq0;
     const float* src = (second ? p.src1 : p.src0) + (second ? kq - kq0 : kq) * 32 + my_chunk * 4;
@@ -270,19 +328,30 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
 #ifdef NZ_ABLATE_WIDE_FETCH        // timing experiment: no activation loads (results wrong)
       ra[j] = f32x4{(float)j, 1.f, 2.f, (float)shift};
 #else
+      // (a branch per load; reading a live row instead and zeroing at the staging measured slower: 14.9 k against 15.4 k)
       ra[j] = my_live[j] ? *reinterpret_cast<const f32x4*>(src + (size_t)(my_row[j] + shift) * cs) : f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
     const u32x4* wsrc = wtile + ((size_t)tap * kqt + kq) * (3 * WIDE_NT * 64);
 #pragma unroll
     for (int j = 0; j < 6; ++j) rb[j] = wsrc[tid + j * 256];
+#if NZ_WIDE_KQ_OUTER       // K order: 32-channel group by group, each group's taps back to back (see above)
+    if (fs + 1 < total) {    // (the cursor never leaves the last step: later fetches repeat it)
+      ++fs;
+      if (!taps_left) { taps_left = vmask; ++kq; }
+      tap = __ffs(taps_left) - 1;
+      taps_left &= taps_left - 1;
+    }
+#else
     if (++kq == kqt) {
       kq = 0;
       if (taps_left) { tap = __ffs(taps_left) - 1; taps_left &= taps_left - 1; }
       else tap = ntaps;
     }
+#endif
   };
   // registers -> LDS
   auto stage_a = [&](int buf, int j) {                 // row slice j: 4 channels -> 8 bytes per piece (activations split here, once)
+    f32x4 (&ra)[8] = ra2[0];
     unsigned char* ab = reinterpret_cast<unsigned char*>(&sA[buf][0][0][0]);
     const int ppos = (tid >> 3) + 32 * j;
     const int off = ppos * 64 + (((my_chunk >> 1) ^ ((ppos >> 2) & 3)) << 4) + (my_chunk & 1) * 8;
@@ -303,6 +372,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
 #endif
   };
   auto stage_b = [&](int buf) {
+    u32x4 (&rb)[6] = rb2[0];
     u32x4* fb = &sB[buf][0][0][0];
 #pragma unroll
     for (int j = 0; j < 6; ++j) fb[tid + j * 256] = rb[j];
@@ -317,15 +387,134 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[g][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  fetch();
+#ifdef NZ_WIDE_STAMPS
+  const bool stamping = blockIdx.x == 0 && blockIdx.y == 0 && tid < 64;
+  unsigned long long wtk[5] = {0, 0, 0, 0, 0}, wts = __builtin_amdgcn_s_memtime();
+#endif
+  fetch(Set0{});
 #pragma unroll
   for (int j = 0; j < 8; ++j) stage_a(0, j);
   stage_b(0);
+#if NZ_WIDE_OVERLAP == 2
+  if (total > 1) fetch(Set1{});
+#endif
   __syncthreads();
+#if NZ_WIDE_OVERLAP == 2
+  // step s: MFMAs on LDS buffer s & 1; the registers of set (s + 1) & 1 (step s + 1's operands, fetched a step ago) are
+  // staged into the other LDS buffer in the MFMAs' gaps; step s + 2's operands are fetched into set s & 1 (staged during
+  // step s - 1).  Two copies of the step's code, one per register set.
+  auto step2 = [&](int s, auto set) {
+    constexpr int par = decltype(set)::value;
+    const int buf = par;
+    WIDE_STAMP(4);
+    // step s + 2's operands: 14 loads of 1 KB per wavefront -- 57 KB per step through the CU's 64-byte-a-cycle vector
+    // memory path, 900 cycles a wavefront issuing them in one burst stands still for (measured: 1,124) -- go out one by
+    // one between the MFMAs: six in the first position group, eight in the last three (the staging fills the gaps of the
+    // groups between).  Behind the last steps the cursor stays where it is (the loads repeat).
+    const bool ahead = fs + 1 < total;
+    const bool second = kq >= kq0;
+    const char* const fsrc = reinterpret_cast<const char*>((second ? p.src1 : p.src0) + (second ? kq - kq0 : kq) * 32) +
+                             (ptrdiff_t)(tap_dy(tap) * p.wd + tap_dx(tap)) * 16 * (second ? p.s1 : p.s0) * 4;
+    const u32x4* const fw = wtile + ((size_t)tap * kqt + kq) * (3 * WIDE_NT * 64);
+    f32x4 (&fa)[8] = ra2[par];
+    u32x4 (&fb)[6] = rb2[par];
+    auto fetch_granule = [&](int i) {
+      if (i < 8) {
+#ifdef NZ_ABLATE_WIDE_FETCH
+        fa[i] = f32x4{(float)i, 1.f, 2.f, (float)second};
+#else
+        fa[i] = *reinterpret_cast<const f32x4*>(fsrc + (second ? rowoff1[i] : rowoff0[i]));
+#endif
+      } else if (i < 14) fb[i - 8] = fw[tid + (i - 8) * 256];
+    };
+    {   // the cursor moves on (scalar selects: no branch in the step)
+      const bool wrap = taps_left == 0;
+      const uint32_t tl = wrap ? vmask : taps_left;
+      const int ntap = __ffs(tl) - 1;
+      kq = ahead ? kq + (wrap ? 1 : 0) : kq;
+      tap = ahead ? ntap : tap;
+      taps_left = ahead ? (tl & (tl - 1)) : taps_left;
+      fs += ahead ? 1 : 0;
+    }
+    WIDE_STAMP(0);                   // loads' addresses
+    f32x4 (&ra)[8] = ra2[par ^ 1];
+    u32x4 (&rb)[6] = rb2[par ^ 1];
+    u32x4 wf[4][3];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) wf[n][piece] = sB[buf][piece][ch * 4 + n][lane];
+    u32x4 xf[2][3];
+    auto load_x = [&](int g, int slot_buf) {
+      const int prow = (ph * 8 + g) * 16 + pos;
+      const int slot = quad ^ ((prow >> 2) & 3);
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) xf[slot_buf][piece] = sA[buf][piece][prow][slot];
+    };
+    load_x(0, 0);
+#ifdef NZ_WIDE_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    WIDE_STAMP(1);                   // first fragments there
+    // The staging of step s + 1 (split arithmetic, LDS stores) rides in the gaps of this step's MFMAs: an MFMA's 16-cycle
+    // gap hides eight cycles of other vector issue and no more, and with one wavefront per SIMD nothing else fills the
+    // time -- so it is cut into 94 granules of at most two vector instructions and a store (per 4-channel row slice: piece
+    // 0 packed and stored, the four first residuals one by one, piece 1, the four second residuals, piece 2; then the
+    // weights' six stores), one behind each MFMA from the second position group on, a scheduling barrier after each.
+    // Unconditional, so that it shares the MFMAs' basic block: behind the last step it stages stale registers nobody reads.
+    float sr[4] = {0.f, 0.f, 0.f, 0.f};
+    int soff = 0;
+    auto stage_granule = [&](int q) {
+      unsigned char* ab = reinterpret_cast<unsigned char*>(&sA[buf ^ 1][0][0][0]);
+      typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+      if (q >= 94) return;
+      if (q >= 88) { (&sB[buf ^ 1][0][0][0])[tid + (q - 88) * 256] = rb[q - 88]; return; }
+      const int j = q / 11, t = q % 11;
+      if (t == 0) {
+        const int ppos = (tid >> 3) + 32 * j;
+        soff = ppos * 64 + (((my_chunk >> 1) ^ ((ppos >> 2) & 3)) << 4) + (my_chunk & 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sr[i] = ra[j][i];
+      }
+      if (t == 0 || t == 5 || t == 10)
+        *reinterpret_cast<u32x2*>(ab + (t / 5) * (WIDE_GROUPS * 16 * 64) + soff) = u32x2{wide_pack_hi16(sr[0], sr[1]), wide_pack_hi16(sr[2], sr[3])};
+      else {
+        const int i = (t - 1) % 5;
+        sr[i] = sr[i] - wide_trunc(sr[i]);
+      }
+    };
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g + 1 < 8) load_x(g + 1, (g + 1) & 1);
+      const u32x4 x0 = xf[g & 1][0], x1 = xf[g & 1][1], x2 = xf[g & 1][2];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+#define NZ_WIDE_STEP(B, X, T)                                                  \
+  acc[g][n] = WIDE_MFMA(wf[n][B], X, acc[g][n]);                               \
+  if (g >= 1) stage_granule((g - 1) * 24 + n * 6 + T);                         \
+  if (g == 0 && (n * 6 + T) % 4 == 2) fetch_granule((n * 6 + T) / 4);          \
+  if (g >= 5 && ((g - 5) * 24 + n * 6 + T) % 9 == 0) fetch_granule(6 + ((g - 5) * 24 + n * 6 + T) / 9); \
+  __builtin_amdgcn_sched_barrier(0);
+        NZ_WIDE_STEP(1, x1, 0) NZ_WIDE_STEP(0, x2, 1) NZ_WIDE_STEP(2, x0, 2) NZ_WIDE_STEP(0, x1, 3) NZ_WIDE_STEP(1, x0, 4) NZ_WIDE_STEP(0, x0, 5)
+#undef NZ_WIDE_STEP
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    WIDE_STAMP(2);                   // MFMAs and staging issued
+    __syncthreads();
+    WIDE_STAMP(3);                   // barrier
+  };
+  for (int s = 0; s < total; s += 2) {
+    step2(s, Set0{});
+    if (s + 1 < total) step2(s + 1, Set1{});
+  }
+#else
   for (int s = 0; s < total; ++s) {
     const int buf = s & 1;
     const bool more = s + 1 < total;
-    if (more) fetch();                                 // the next step's operands fly under this step's MFMAs
+    if (more) fetch(Set0{});                           // the next step's operands fly under this step's MFMAs
+    f32x4 (&ra)[8] = ra2[0];
+    u32x4 (&rb)[6] = rb2[0];
     u32x4 wf[4][3];
 #pragma unroll
     for (int n = 0; n < 4; ++n)
@@ -343,6 +532,15 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     for (int g = 0; g < 8; ++g) {
       if (g + 1 < 8) load_x(g + 1, (g + 1) & 1);             // the next group's fragments fly under this group's MFMAs
       const u32x4 x0 = xf[g & 1][0], x1 = xf[g & 1][1], x2 = xf[g & 1][2];
+#if NZ_WIDE_INTERLEAVE
+      // small terms first; the four column tiles' chains side by side (a term of each in turn: an MFMA that waits for the
+      // one before it issues late)
+#define NZ_WIDE_TERM(B, X)                                                          \
+  _Pragma("unroll") for (int n = 0; n < 4; ++n) acc[g][n] = wide_mfma(wf[n][B], X, acc[g][n]); \
+  __builtin_amdgcn_sched_barrier(0);
+      NZ_WIDE_TERM(1, x1) NZ_WIDE_TERM(0, x2) NZ_WIDE_TERM(2, x0) NZ_WIDE_TERM(0, x1) NZ_WIDE_TERM(1, x0) NZ_WIDE_TERM(0, x0)
+#undef NZ_WIDE_TERM
+#else
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         acc[g][n] = wide_mfma(wf[n][1], x1, acc[g][n]);       // small terms first; one dependent chain
@@ -353,6 +551,7 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
         acc[g][n] = wide_mfma(wf[n][0], x0, acc[g][n]);
         __builtin_amdgcn_sched_barrier(0);                     // keep the chain together (net_dev.hpp)
       }
+#endif
     }
     if (more) {                                                // staging after the MFMAs: slices between the chains were slower
 #pragma unroll
@@ -361,7 +560,15 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     }
     __syncthreads();
   }
+#endif
 
+#ifdef NZ_WIDE_STAMPS
+  if (stamping && lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_wide_stamps[i], wtk[i]);
+    atomicAdd(&g_wide_stamps[5], (unsigned long long)total);
+    atomicAdd(&g_wide_stamps[6], 1ull);
+  }
+#endif
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int group = gbase + ph * 8 + g;
@@ -1960,6 +2167,22 @@ nz_status nz_boardnet_set_weights(nz_boardnet* h, const float* const* weights, i
 }
 
 int64_t nz_boardnet_flops(const nz_boardnet* h) { return h ? h->flops : 0; }
+
+// Diagnostic (-DNZ_WIDE_STAMPS builds only; NZ_ERR_STATE otherwise): conv_wide_kernel's phase ticks summed over its launches
+// so far: [0] loads issued, [1] first fragments, [2] MFMAs + staging, [3] barrier, [4] loop overhead, [5] K steps, [6] launches.
+nz_status nz_boardnet_wide_stamps(uint64_t* out8) {
+#ifdef NZ_WIDE_STAMPS
+  if (!out8) return NZ_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return NZ_ERR_HIP;
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wide_stamps), sizeof(h)) != hipSuccess) return NZ_ERR_HIP;
+  for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  return NZ_OK;
+#else
+  (void)out8;
+  return NZ_ERR_STATE;
+#endif
+}
 
 nz_status nz_boardnet_fused(nz_boardnet* h, int32_t enable, int32_t* available) {
   if (!h) return NZ_ERR_ARG;
