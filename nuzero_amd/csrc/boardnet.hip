@@ -440,10 +440,6 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
     f32x4 (&ra)[8] = ra2[par ^ 1];
     u32x4 (&rb)[6] = rb2[par ^ 1];
     u32x4 wf[4][3];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-      for (int piece = 0; piece < 3; ++piece) wf[n][piece] = sB[buf][piece][ch * 4 + n][lane];
     u32x4 xf[2][3];
     auto load_x = [&](int g, int slot_buf) {
       const int prow = (ph * 8 + g) * 16 + pos;
@@ -451,7 +447,11 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
 #pragma unroll
       for (int piece = 0; piece < 3; ++piece) xf[slot_buf][piece] = sA[buf][piece][prow][slot];
     };
-    load_x(0, 0);
+    load_x(0, 0);                    // (the first chain's operands first: the MFMAs start when they are there)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int piece = 0; piece < 3; ++piece) wf[n][piece] = sB[buf][piece][ch * 4 + n][lane];
 #ifdef NZ_WIDE_STAMPS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -491,9 +491,19 @@ __global__ __launch_bounds__(256) void conv_wide_kernel(ConvArgs p) {
       for (int n = 0; n < 4; ++n) {
 #define NZ_WIDE_STEP(B, X, T)                                                  \
   acc[g][n] = WIDE_MFMA(wf[n][B], X, acc[g][n]);                               \
-  if (g >= 1) stage_granule((g - 1) * 24 + n * 6 + T);                         \
-  if (g == 0 && (n * 6 + T) % 4 == 2) fetch_granule((n * 6 + T) / 4);          \
-  if (g >= 5 && ((g - 5) * 24 + n * 6 + T) % 9 == 0) fetch_granule(6 + ((g - 5) * 24 + n * 6 + T) / 9); \
+  {                                                                            \
+    /* the 94 staging granules spread evenly over the 168 gaps behind MFMAs 24..191, the 14 loads over the 74 gaps they leave */ \
+    constexpr int SG = 94, FG = 14, GAPS = 168, FREE = GAPS - SG;              \
+    const int m = g * 24 + n * 6 + T - 24;                                     \
+    if (m >= 0) {                                                              \
+      const int q = m * SG / GAPS;                                             \
+      if (m == 0 || q != (m - 1) * SG / GAPS) stage_granule(q);                \
+      else {                                                                   \
+        const int r = m - ((m - 1) * SG / GAPS + 1), f = (r * FG + FREE - 1) / FREE; \
+        if (f < FG && f * FREE / FG == r) fetch_granule(f);                    \
+      }                                                                        \
+    }                                                                          \
+  }                                                                            \
   __builtin_amdgcn_sched_barrier(0);
         NZ_WIDE_STEP(1, x1, 0) NZ_WIDE_STEP(0, x2, 1) NZ_WIDE_STEP(2, x0, 2) NZ_WIDE_STEP(0, x1, 3) NZ_WIDE_STEP(1, x0, 4) NZ_WIDE_STEP(0, x0, 5)
 #undef NZ_WIDE_STEP
