@@ -410,7 +410,7 @@ __device__ __forceinline__ void scs_legal_mask_wave(const ScsRules& r, const Scs
 // position's first row of the network's input rows (boardnet.hip: row = cell * 16 + ..., `stride` floats per row,
 // channels contiguous), so element (c, t) lives at img[t * 16 * stride + c] -- the leaf batch is then already in
 // the layout the conv kernels read and needs no conversion pass.
-template <bool ROWS>
+template <bool ROWS, bool LDS_IMG = false>       // LDS_IMG: the image is in LDS (one wavefront's LDS operations keep their order)
 __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const ScsState& s, float* __restrict__ img, int stride,
                                                      int lane) {
   auto at = [&](int c, int t) -> float& { return ROWS ? img[(size_t)t * 16 * stride + c] : img[c * r.tiles + t]; };
@@ -430,7 +430,37 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
     }
     return v;
   };
-  if constexpr (ROWS) {
+  const int nc4 = (r.channels + 3) >> 2;               // 16-byte chunks of a tile's row
+  if (ROWS && T <= 64 && 2 * nc4 <= 64) {
+    // Two tiles' rows per pass, a 16-byte chunk per lane: the planes that depend on the state only are made once (the
+    // same on every tile), tile t's terrain sits in lane t and is handed round with v_readlane -- the pass is readlanes,
+    // selects and one store, with no LDS read to wait for (a tile-by-tile loop with its terrain reads was 4 k cycles of
+    // the persistent route's 9 k per leaf).
+    float tr[3] = {0.f, 0.f, 0.f};
+    if (lane < T) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) tr[k] = r.terrain_f[lane][k];
+    }
+    const int second = lane >= nc4 ? 1 : 0, c = (lane - second * nc4) * 4;
+    typedef float img4 __attribute__((ext_vector_type(4)));
+    img4 dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dv[i] = c + i < r.channels ? dense(c + i) : 0.0f;
+    for (int t0 = 0; t0 < T; t0 += 2) {
+      const int t1 = t0 + 1 < T ? t0 + 1 : t0;
+      img4 v = dv;
+      if (c == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const uint32_t bits = __builtin_bit_cast(uint32_t, tr[k]);
+          const uint32_t a = __builtin_amdgcn_readlane(bits, t0), b = __builtin_amdgcn_readlane(bits, t1);
+          v[k] = __builtin_bit_cast(float, second ? b : a);
+        }
+      }
+      const int t = t0 + second;
+      if (lane < 2 * nc4 && t < T) *reinterpret_cast<img4*>(img + (size_t)t * 16 * stride + c) = v;
+    }
+  } else if constexpr (ROWS) {
     // a tile's channels are contiguous: lane = channel (and channel + 64), tile by tile -- no division per element
     const int c0 = lane, c1 = lane + 64;
     const float v0 = dense(c0), v1 = dense(c1);
@@ -449,7 +479,8 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
       at(c, t) = c < 3 ? r.terrain_f[t][c] : dense(c);
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
+  if constexpr (LDS_IMG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
   for (int p = 0; p < 2; ++p)
     if (lane < r.n_vp[p]) at(3 + p, r.vp[p][lane]) = 1.0f;
   for (int p = 0; p < 2; ++p) {                 // the next three reinforcements of each player, schedule order

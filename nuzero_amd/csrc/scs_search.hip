@@ -1493,7 +1493,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       // one looks the leaf up in the cache and stages its planes; they meet before the planes are split.
       ++pass;
       if (lane == 0) flags[7] = base;             // (what the helper's own overflow check needs)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (the helper reads LDS only: no wait for the stores to the tree)
       if (lane == 0) __hip_atomic_store(go, pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       float* const pol = net + pol_off;
       // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
@@ -1549,7 +1549,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       uint64_t dig_hi = 0, dig_lo = 0;
       if (hit && rec >= 0) {                    // (the test hook records every evaluation the search consumed: the planes' digest)
         float* const stage = net + q.stage_off;
-        scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
+        scs_state_image_wave<true, true>(R, sc, stage, q.inp >> 4, lane);
         scs_sync<false>();
         image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
         scs_sync<false>();
@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       if (!hit) {
         // the leaf's planes (generate_network_input, SCS_Game.py:1507) as float32 rows over the trunk buffers' space
         float* const stage = net + q.stage_off;
-        scs_state_image_wave<true>(R, sc, stage, q.inp >> 4, lane);
+        scs_state_image_wave<true, true>(R, sc, stage, q.inp >> 4, lane);
         scs_sync<false>();
         if (rec >= 0) image_hash_wave(stage, q.inp, q.in_channels, hw, lane, dig_hi, dig_lo);
       }
@@ -1798,7 +1798,7 @@ __global__ __launch_bounds__(PERSIST_THREADS) void persist_kernel(SearchParams p
 #endif
     while ((gv = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == pass) __builtin_amdgcn_s_sleep(NZ_PERSIST_GO_SLEEP);
     if (gv == PERSIST_EXIT) break;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     pass = gv;
     // a leaf that needs an evaluation: its legal mask and list (the leader meanwhile looks it up in the cache and stages
     // its planes), then -- unless the cache had it -- half of the split into pieces and half of every layer
