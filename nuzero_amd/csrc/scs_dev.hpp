@@ -414,19 +414,44 @@ template <bool ROWS, bool LDS_IMG = false>       // LDS_IMG: the image is in LDS
 __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const ScsState& s, float* __restrict__ img, int stride,
                                                      int lane) {
   auto at = [&](int c, int t) -> float& { return ROWS ? img[(size_t)t * 16 * stride + c] : img[c * r.tiles + t]; };
-  const Scs game(r, const_cast<ScsState&>(s));
   const int T = r.tiles, S = r.stacking;
   const int per_player = 3 * S * 3;
   const int unit_base = 5 + 36, target_plane = unit_base + 2 * per_player, att_base = target_plane + 1,
             phase_base = att_base + S;
+  // Everything the image needs from the state and the rules is read HERE, before anything depends on it: section by section
+  // the reads were a chain of some forty dependent LDS round trips (7.7 k cycles per leaf on the persistent route).
+  const int sub_phase = s.sub_phase, turn = s.turn, turns = r.turns, player = s.player, target = s.target;
+  const int nu = r.n_units, n_att = s.n_attackers, nv0 = r.n_vp[0], nv1 = r.n_vp[1];
+  const bool isu = lane < nu;
+  const int u_st = isu ? (int)s.status[lane] : -1, u_pl = isu ? (int)r.u_player[lane] : -1;
+  const int u_tile_raw = isu ? (int)s.tile[lane] : 0, u_tile = u_tile_raw >= 0 ? u_tile_raw : 0;
+  const int u_att = isu ? (int)r.u_attack[lane] : 0, u_def = isu ? (int)r.u_defense[lane] : 0, u_mov = isu ? (int)s.mov[lane] : 0;
+  const int u_turn = isu ? (int)r.u_turn[lane] : 0;
+  const int vp0 = lane < nv0 ? (int)r.vp[0][lane] : -1, vp1 = lane < nv1 ? (int)r.vp[1][lane] : -1;
+  const int a_u = lane < n_att ? (int)s.attackers[lane] : -1;
+  auto level_in = [&](int t, int u) {            // Tile.get_stacking_level: the first place of unit u in tile t's stack
+    const int n = s.stack_n[t];
+    int st_[SCS_MAX_STACK];
+#pragma unroll
+    for (int i = 0; i < SCS_MAX_STACK; ++i) st_[i] = s.stack[t][i];
+    int lvl = 0;
+#pragma unroll
+    for (int i = SCS_MAX_STACK - 1; i >= 0; --i) lvl = (i < n && st_[i] == u) ? i : lvl;
+    return lvl;
+  };
+  const int u_lvl = level_in(u_tile, lane);
+  const int a_us = a_u >= 0 ? a_u : 0;
+  const int a_st = (int)s.status[a_us], a_tile_raw = (int)s.tile[a_us], a_tile = a_tile_raw >= 0 ? a_tile_raw : 0;
+  const int a_lvl = level_in(a_tile, a_us);
+  const float turn_frac = (float)((double)turn / (double)turns);
   // planes that are dense: written whole; every other plane is zero-filled first
   auto dense = [&](int c) {                      // the value of a plane that is the same on every tile (terrain: per tile)
     float v = 0.0f;
     if (c >= phase_base) {
       const int k = c - phase_base;
-      if (k < 4) v = k == s.sub_phase ? 1.0f : 0.0f;
-      else if (k == 4) v = (float)((double)s.turn / (double)r.turns);
-      else v = s.player == 1 ? -1.0f : 1.0f;
+      if (k < 4) v = k == sub_phase ? 1.0f : 0.0f;
+      else if (k == 4) v = turn_frac;
+      else v = player == 1 ? -1.0f : 1.0f;
     }
     return v;
   };
@@ -481,40 +506,37 @@ __device__ __forceinline__ void scs_state_image_wave(const ScsRules& r, const Sc
   }
   if constexpr (LDS_IMG) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // the scattered writes below land after the fill
-  for (int p = 0; p < 2; ++p)
-    if (lane < r.n_vp[p]) at(3 + p, r.vp[p][lane]) = 1.0f;
+  if (vp0 >= 0) at(3, vp0) = 1.0f;
+  if (vp1 >= 0) at(4, vp1) = 1.0f;
   for (int p = 0; p < 2; ++p) {                 // the next three reinforcements of each player, schedule order
-    const bool queued = lane < r.n_units && r.u_player[lane] == p && s.status[lane] == SCS_QUEUED;
+    const bool queued = isu && u_pl == p && u_st == SCS_QUEUED;
     unsigned long long m = __ballot(queued);
     for (int shown = 0; shown < 3 && m; ++shown) {
-      const int u = __ffsll((long long)m) - 1;
+      const int u = __ffsll((long long)m) - 1;              // (wave-uniform: the unit's numbers come out of its lane)
       m &= m - 1;
-      const double importance = (double)((r.turns + 1) - (r.u_turn[u] - s.turn)) / (double)(r.turns + 1);
+      const int ut = __builtin_amdgcn_readlane(u_turn, u);
+      const float ua = (float)__builtin_amdgcn_readlane(u_att, u), ud = (float)__builtin_amdgcn_readlane(u_def, u),
+                  um = (float)__builtin_amdgcn_readlane(u_mov, u);
+      const double importance = (double)((turns + 1) - (ut - turn)) / (double)(turns + 1);
       const int o = 5 + p * 18 + shown * 6;
       for (int t = lane; t < T; t += 64) {
         if (r.arrival[u][t]) {
-          at(o, t) = (float)r.u_attack[u];
-          at(o + 1, t) = (float)r.u_defense[u];
-          at(o + 2, t) = (float)s.mov[u];
+          at(o, t) = ua;
+          at(o + 1, t) = ud;
+          at(o + 2, t) = um;
         }
         at(o + 3, t) = at(o + 4, t) = at(o + 5, t) = (float)importance;
       }
     }
   }
-  if (lane < r.n_units) {
-    const int u = lane, st = s.status[u];
-    if (st >= SCS_AVAILABLE && st <= SCS_ATTACKED) {
-      const int o = unit_base + r.u_player[u] * per_player + st * S * 3 + game.level_of(u) * 3, t = s.tile[u];
-      at(o, t) = (float)r.u_attack[u];
-      at(o + 1, t) = (float)r.u_defense[u];
-      at(o + 2, t) = (float)s.mov[u];
-    }
+  if (isu && u_st >= SCS_AVAILABLE && u_st <= SCS_ATTACKED) {
+    const int o = unit_base + u_pl * per_player + u_st * S * 3 + u_lvl * 3;
+    at(o, u_tile) = (float)u_att;
+    at(o + 1, u_tile) = (float)u_def;
+    at(o + 2, u_tile) = (float)u_mov;
   }
-  if (lane == 0 && s.target >= 0) at(target_plane, s.target) = 1.0f;
-  if (lane < s.n_attackers) {
-    const int u = s.attackers[lane];
-    if (s.status[u] != SCS_DEAD) at(att_base + game.level_of(u), s.tile[u]) = 1.0f;
-  }
+  if (lane == 0 && target >= 0) at(target_plane, target) = 1.0f;
+  if (a_u >= 0 && a_st != SCS_DEAD) at(att_base + a_lvl, a_tile) = 1.0f;
 }
 
 // Scs::step by a whole wavefront: lane 0 applies the action (a handful of stores), the turn

@@ -1495,6 +1495,9 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
       if (lane == 0) flags[7] = base;             // (what the helper's own overflow check needs)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // (the helper reads LDS only: no wait for the stores to the tree)
       if (lane == 0) __hip_atomic_store(go, pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef NZ_PERSIST_STAMP_GO    // diagnostic of a diagnostic: the leaf's bookkeeping up to the helper's wake-up, reported in the "slowest" slot
+      PSTAMP(9);
+#endif
       float* const pol = net + pol_off;
       // (action i = plane * hw + cell; lanes walk i = lane, lane + 64, ... without a division per entry)
       const int cell0 = lane % hw, plane0 = lane / hw, dcell = 64 % hw, dplane = 64 / hw;
@@ -1725,7 +1728,11 @@ __device__ __forceinline__ void persist_leader(const SearchParams& p, const Pers
     tk[8] = __builtin_amdgcn_s_memtime() - t_begin;        // the game's whole move
     for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)&p.counters[2 + i], tk[i]);
     for (int i = 6; i < 9; ++i) atomicAdd((unsigned long long*)&p.counters[5 + i], tk[i]);
+#ifdef NZ_PERSIST_STAMP_GO
+    atomicAdd((unsigned long long*)&p.counters[14], tk[9]);
+#else
     atomicMax((unsigned long long*)&p.counters[14], tk[8]);  // the slowest (game, move) of the round
+#endif
     // inside the network (the leader's half): K loops, epilogues, waiting for the helper -- in the cache counters' words
     // (a diagnostic build runs without the cache)
     for (int i = 0; i < 3; ++i) atomicAdd((unsigned long long*)&p.counters[8 + i], tk[10 + i]);
