@@ -42,7 +42,7 @@ Extra keys (N = 1)
   scs_config4_round4  scs_config4 with four games per concurrent tree in one round (nz_scs_search_play_round: a tree
                     whose game has ended starts the round's next game)
   scs_config5       BASELINE.json configs[4] on one GPU, bounded: SCS 10x10, RecurrentNet(256 x 2, recall) x 16 iterations,
-                    400 sims/move, 256 games x their first decision; expansions/s and the network's rate
+                    400 sims/move, 1024 games x their first decision; expansions/s and the network's rate
   ttt_config3_share BASELINE.json configs[2]'s share of one GPU: 1024 concurrent Tic-Tac-Toe games, 400 sims/move
   cpu_baseline      the CPU oracle (oracle/search.py + oracle/net.py, the restatement of the reference's
                     Explorer/Gamer path) on this box's host cores, one process per core, on a bounded sample
@@ -220,12 +220,15 @@ def scs_config4(device, games_per_tree=1):
     return out
 
 
-def scs_config5(device, games=256, moves=1):
+def scs_config5(device, games=1024, moves=1):
     """BASELINE.json configs[4] on one GPU, bounded: SCS 10x10 map, RecurrentNet(86 -> 21, 256 filters, 2 blocks, recall,
     relu value head; Run.py:148) with 16 recurrent iterations, 400 simulations per move -- `games` games, the first
     `moves` decisions of each (a whole game is ~120 decisions x 400 evaluations x 9 GFLOP).  Wave-by-wave route: the
-    per-layer board-net kernels (a 256-wide net on 100 cells has no one-launch form); with 256 concurrent games a
-    wave's leaves fill the 256-position tiles of conv_wide_kernel (split-bf16 MFMA)."""
+    per-layer board-net kernels (a 256-wide net on 100 cells has no one-launch form).  configs[4] does not fix the number
+    of concurrent games: conv_wide_kernel's tiles are (cell, 128 channels, 256 positions), so 256 games are 200 workgroups
+    -- 56 of the 256 CUs idle and the corner / edge cells' workgroups (4 / 6 taps) waiting for the interior's (9) --
+    while 1024 games are 800 workgroups that the dispatcher evens out over the chip (same box: 16.3 k expansions/s at 256
+    games, 17.5 k at 512, 19.2 k at 768, 22.0 k at 1024, 21.4 k at 1280; scripts/ab_cfg5_games.sh)."""
     import torch
     from nuzero_amd.boardnet import BoardNet
     from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay
@@ -240,7 +243,9 @@ def scs_config5(device, games=256, moves=1):
                    value_activation="relu", max_batch=games, device=device)
     net.set_weights(synthetic_weights(0, recurrent_net_param_shapes(cfg.channels, cfg.planes, 256, 2, True)), 16)
     sp = ScsSelfPlay(cfg, search, games, device=device)
-    sp.play_native(net, range(games), max_moves=1)
+    warm = ScsSelfPlay(cfg, dict(search, Simulation={"mcts_simulations": 8, "keep_subtree": True}), games, device=device)
+    warm.play_native(net, range(games), max_moves=1)       # untimed: every kernel of the route has run once
+    warm.close()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = sp.play_native(net, range(10 ** 5, 10 ** 5 + games), max_moves=moves)

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 from nuzero_amd.boardnet import BoardNet  # noqa: E402
 from nuzero_amd.scs import ScsGameConfig, ScsSelfPlay  # noqa: E402
 from nuzero_amd.weights import synthetic_weights, recurrent_net_param_shapes  # noqa: E402
-games = int(os.environ.get("NZ_CFG5_GAMES", "256"))
+games = int(os.environ.get("NZ_CFG5_GAMES", "1024"))
 cfg = ScsGameConfig(os.path.join(REPO, "tests", "golden", "scs_configs", "ten_by_ten.yml"))
 search = {"Simulation": {"mcts_simulations": int(os.environ.get("NZ_CFG5_SIMS", "400")), "keep_subtree": True},
           "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},

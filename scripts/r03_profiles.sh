@@ -33,12 +33,12 @@ timeout -k 10 300 python3 $R/bench_scs.py --games 1024 --cache 1048576 > $O/scs_
 cat $O/persist_netbench.txt
 NZ_LIB_PATH=$R/scripts/ablate/lib_pstamps.so timeout -k 10 300 python3 $R/bench_scs.py --games 1024 > $O/scs_stamps.log 2>&1
 tail -1 $O/scs_1024.log | cut -c1-600
-# configs[4] (10x10, RecurrentNet 256 x 2 x 16 iterations): kernel stats of one decision of 256 games, conv_wide_kernel's
+# configs[4] (10x10, RecurrentNet 256 x 2 x 16 iterations): kernel stats of one decision of 1024 games, conv_wide_kernel's
 # K-step stamps, and the round-2 form of the kernel on the same box
 timeout -k 10 300 python3 $R/scripts/cfg5_standalone.py > $O/cfg5_plain.log 2>&1 || exit 1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_c5 -- python3 $R/scripts/cfg5_standalone.py > $O/cfg5_rocprof.log 2>&1 || exit 1
 cp $(ls /tmp/p_c5/*/*kernel_stats.csv | head -1) $O/cfg5_kernel_stats.csv
-( echo "== product build (scripts/cfg5_standalone.py: 256 games x their first decision x 400 simulations)"; tail -1 $O/cfg5_plain.log
+( echo "== product build (scripts/cfg5_standalone.py: 1024 games x their first decision x 400 simulations)"; tail -1 $O/cfg5_plain.log
   echo "== K-step stamps (-DNZ_WIDE_STAMPS; ticks per step of workgroup 0's wavefront 0: a corner cell)"; NZ_LIB_PATH=$R/scripts/ablate/lib_wstamps.so timeout -k 10 300 python3 $R/scripts/cfg5_standalone.py 2>&1 | tail -1
   echo "== round-2 form of conv_wide_kernel (-DNZ_WIDE_OVERLAP=0 -DNZ_WIDE_XCD=0 -DNZ_WIDE_KQ_OUTER=0)"; NZ_LIB_PATH=$R/scripts/ablate/lib_wnoover.so timeout -k 10 300 python3 $R/scripts/cfg5_standalone.py 2>&1 | tail -1 ) > $O/cfg5_conv_wide.txt
 cat $O/cfg5_conv_wide.txt
