@@ -236,7 +236,10 @@ __device__ __forceinline__ float np_sum_sparse_f32_wave(const SearchParams& p, c
   }
   return st0;
 }
-__device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 here (children of one node)
+// numpy's pairwise sum of a dense float64 vector (the children of one node: n <= MAXC_LIMIT = 256): blocks of at most 128
+// entries on eight running sums; a longer vector is halved (the left half a multiple of eight) and the halves' sums are
+// added -- two levels of halving reach every n <= 256 (no recursion on the device: DEPTH counts them down)
+__device__ inline double np_sum_f64_block(const double* v, int n) {     // n <= 128
   if (n < 8) {
     double r = 0.0;
     for (int i = 0; i < n; ++i) r = r + v[i];
@@ -251,6 +254,19 @@ __device__ double np_sum_f64(const double* v, int n) {     // dense, n <= 128 he
   for (; i < n; ++i) res = res + v[i];
   return res;
 }
+template <int DEPTH = 2>
+__device__ inline double np_sum_f64(const double* v, int n) {
+  if constexpr (DEPTH > 0) {
+    if (n > 128) {
+      int n2 = n / 2;
+      n2 -= n2 % 8;
+      const double left = np_sum_f64<DEPTH - 1>(v, n2);
+      return left + np_sum_f64<DEPTH - 1>(v + n2, n - n2);
+    }
+  }
+  return np_sum_f64_block(v, n);
+}
+static_assert(MAXC_LIMIT <= 256, "np_sum_f64 halves a vector at most twice");
 
 __device__ __forceinline__ const ScsRules& rules_of(const SearchParams& p, int g) {
   return p.rules[p.rules_row ? p.rules_row[g] : 0];

@@ -208,12 +208,15 @@ def test_gamer_and_network_manager_surface_for_scs(hexnet):
     assert np.max(np.abs(logits.cpu().numpy() - p)) / scale < 1e-5 and np.max(np.abs(value.cpu().numpy() - v)) < 1e-5
 
 
-@pytest.mark.parametrize("name,sims,n_games", [("wide_arrival_10x10", 24, 4), ("reference_test_config", 8, 3)])
+@pytest.mark.parametrize("name,sims,n_games", [("wide_arrival_10x10", 24, 4), ("reference_test_config", 8, 3),
+                                               ("many_units_10x10", 12, 3)])
 def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
     """No fixed limits on the search: the reference's own test_config.yml (23 units, stacking 3: games of ~290 decisions,
     past the 256 a record used to hold) and a map whose opening positions have 90 legal actions (more than the 64 lanes
     of a wavefront: children are handled in chunks) play on the device exactly as on the oracle -- root noise, float32
-    pairwise sums and PUCT ties included."""
+    pairwise sums and PUCT ties included; so does a map with 27 units on one side, whose movement phase has more than 128 legal
+    actions (three chunks; with softmax moves up to there, select_action's softmax sums more than the 128 values numpy
+    adds in one pairwise block)."""
     import torch
     from scs_eval import evaluate_image
     from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
@@ -228,16 +231,18 @@ def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
         return (torch.from_numpy(np.stack([o[0] for o in out])), torch.from_numpy(np.array([o[1] for o in out], np.float32)))
 
     search = {"Simulation": {"mcts_simulations": sims, "keep_subtree": True}, "UCT": {"pb_c_base": 10000, "pb_c_init": 1.15},
-              "Exploration": {"number_of_softmax_moves": 2, "epsilon_softmax_exploration": 0.1,
+              "Exploration": {"number_of_softmax_moves": 40 if name == "many_units_10x10" else 2,
+                              "epsilon_softmax_exploration": 0.1,
                               "epsilon_random_exploration": 0.05, "value_factor": 1,
                               "root_exploration_distribution": "gamma", "root_exploration_fraction": 0.2,
                               "root_dist_alpha": 0.3, "root_dist_beta": 1}}
     seeds = list(range(70, 70 + n_games))
     sp = ScsSelfPlay(cfg, search, n_games)
-    assert sp.MAX_CHILDREN % 64 == 0 and sp.MAX_CHILDREN >= (128 if name == "wide_arrival_10x10" else 64)
+    assert sp.MAX_CHILDREN % 64 == 0
+    assert sp.MAX_CHILDREN >= {"wide_arrival_10x10": 128, "many_units_10x10": 192}.get(name, 64)
     r = sp.play(device_ev, seeds)
     sp.close()
-    most_children, longest = 0, 0
+    most_children, longest, softmax_over_128 = 0, 0, 0
     for g in range(n_games):
         game, trace = ScsGame(ocfg), []
         osearch.play_game(game, lambda gm: evaluate_image(gm.state_image()[0], A), search, np.random.RandomState(seeds[g]),
@@ -247,6 +252,7 @@ def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
         for m, mv in enumerate(trace):
             k = len(mv["child_actions"])
             most_children = max(most_children, k)
+            softmax_over_128 += k > 128 and m < search["Exploration"]["number_of_softmax_moves"]
             assert r["actions"][g, m] == mv["action"], (g, m)
             assert r["child_action"][g, m, :k].tolist() == mv["child_actions"]
             assert r["child_visit"][g, m, :k].tolist() == mv["child_visits"], (g, m)
@@ -254,6 +260,8 @@ def test_scs_search_limits_come_from_the_game_description(name, sims, n_games):
             assert r["child_value_sum"][g, m, :k].tolist() == mv["child_value_sums"]
     if name == "wide_arrival_10x10":
         assert most_children > 64
+    elif name == "many_units_10x10":
+        assert most_children > 128 and softmax_over_128 > 0
     else:
         assert longest > 150 and sp.MAX_MOVES > 256
 
