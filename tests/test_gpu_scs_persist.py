@@ -100,6 +100,38 @@ def test_persistent_route_equals_the_oracle_replay_and_the_wave_route(arch, hexn
     sp.close(); net.close()
 
 
+@pytest.mark.parametrize("name,sims,softmax_moves", [("many_units_5x6", 16, 30)])
+def test_persistent_route_with_more_than_64_children(name, sims, softmax_moves):
+    """Positions with 70-100 legal actions on a board small enough for the persistent kernel (19 units against 4 on
+    5 x 6 cells: the kernel variant that holds a node's children in chunks of 64 lanes): the persistent route
+    replays exactly on the oracle from its own recorded evaluations, and plays the games of the wave-by-wave route."""
+    from nuzero_amd.scs import ScsSelfPlay, ScsGameConfig
+    path = os.path.join(GOLDEN, "scs_configs", name + ".yml")
+    cfg = ScsGameConfig(path)
+    G = 6
+    net, w = _net(cfg, "convnet", 32, 2, seed=47, gain=2.5, max_batch=G)
+    search = a1_search(sims, number_of_softmax_moves=softmax_moves, epsilon_softmax_exploration=0.1,
+                       epsilon_random_exploration=0.05, root_exploration_fraction=0.25, root_dist_alpha=0.3)
+    seeds = list(range(2300, 2300 + G))
+    sp = ScsSelfPlay(cfg, search, G)
+    assert sp.MAX_CHILDREN > 64
+    sp.persistent(1)
+    sp.record(range(G), sims * (sp.MAX_MOVES + 1))
+    rp = sp.play_native(net, seeds)
+    assert sp.persistent() is True
+    assert int(rp["n_children"].max()) > 64
+    recs = sp.records()
+    _game_properties(path, rp, range(G))
+    moves = _replay_recorded(path, search, seeds, rp, recs, range(G), name)
+    assert moves == int(rp["lengths"].sum())
+    sp.record([], 0)
+    sp.persistent(0)
+    rw = sp.play_native(net, seeds)
+    assert sp.persistent() is False
+    _same_games(rp, rw, [(g, g) for g in range(G)], name)
+    sp.close(); net.close()
+
+
 def test_persistent_route_on_baseline_config_4():
     """BASELINE.json configs[3] at full size on the persistent route: 1024 games x 200 simulations per move, ConvNet(32
     filters x 8 layers).  Properties of all 1024 games through the oracle rules; exact oracle replay of 4 games on the
