@@ -288,7 +288,8 @@ def ttt_config3_share(cfg_sims, weights, iters, device, games=1024, sims=400):
     out = {"value": rounds * games / dt, "unit": "games/s", "expansions_per_s": exp / dt,
            "simulations_per_s": sim / dt, "rounds": rounds, "games_per_round": games,
            "sims_per_move": sims,
-           "note": "1024 games are 64 workgroups of 16: a quarter of the chip's CUs (one 16-game tile per CU)",
+           "note": "1024 games are spread four to a workgroup over 256 workgroups (TreeParams.slots_per_wg: packed 16 to a "
+                   "workgroup they would keep a quarter of the CUs busy); a network pass still costs 16 columns of MFMAs",
            "workload": "Tic_Tac_Toe, 400 sims/move, 1024 concurrent games (one GPU's share of 8192 over 8 GPUs)"}
     eng.close()
     return out

@@ -81,6 +81,8 @@ struct TreeParams {
   int32_t softmax_moves;
   double eps_softmax, eps_random;
   int32_t sims_per_cycle;  // persistent kernel: simulations a game may run between two network passes
+  int32_t slots_per_wg;    // persistent kernel: game slots a workgroup plays (1..16 of its 16 network rows): fewer slots
+                           // than 16 x CUs are spread over all CUs rather than packed into a quarter of them
   int32_t max_cycles;      // persistent kernel: tree/network cycles a workgroup may run before it gives up
                            // (error flag 64) -- a bound every wave reaches, whatever goes wrong
   int32_t* error_flag;
@@ -105,7 +107,7 @@ void launch_export_states(const TreeParams& p, float* states, hipStream_t s);
 void launch_export_visits(const TreeParams& p, int32_t* visits, int32_t* actions, int32_t* tree_size,
                           int32_t* n_children, double* bias, hipStream_t s);
 
-int selfplay_blocks(int n_games);
+int selfplay_blocks(int n_slots, int slots_per_wg);
 // stamps != nullptr selects the diagnostic build ([blocks][4] phase ticks, see selfplay.hip)
 void launch_selfplay(const TreeParams& p, const struct NetProgram* prog_dev, int n_layers, const float* weights,
                      const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s);

@@ -325,7 +325,7 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   A(bias_tab, e->tab_len); A(sqrt_tab, e->tab_len);
   A(e->d_noise, G * TTT_ACTIONS); A(e->d_uniforms, G * 3);
   A(e->d_game_noise, GTA); A(e->d_game_uniforms, GT * 3);
-  A(e->d_stamps, (size_t)selfplay_blocks(n_slots) * 6);
+  A(e->d_stamps, (size_t)n_slots * 6);                 // (one workgroup per slot at most)
   A(p.next_game, 1);
   A(e->prog_dev, 1);
 #undef A
@@ -347,6 +347,15 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   p.eps_random = cfg->epsilon_random_exploration;
   p.sims_per_cycle = 16;
   if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
+  {   // a workgroup's 16 network rows are filled only when there are 16 slots for every CU: fewer slots are spread over the
+      // chip (1024 slots: 4 to each of 256 workgroups instead of 16 to each of 64 -- a pass costs the same matrix
+      // instructions however many of its columns hold a leaf, and a tree phase waits for the slowest of fewer rows)
+    hipDeviceProp_t prop;
+    int n_cu = 256;
+    if (hipGetDeviceProperties(&prop, e->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    p.slots_per_wg = std::min(16, std::max(1, (n_slots + n_cu - 1) / n_cu));
+    if (const char* v = getenv("NZ_SLOTS_PER_WG")) p.slots_per_wg = std::min(16, std::max(1, atoi(v)));   // tuning experiments
+  }
   {   // every cycle finishes at least one simulation or one move of every live row of the workgroup
     const double games_per_slot = std::ceil((double)p.n_games / (double)p.n_slots) + 2.0;
     const double bound = 16.0 * games_per_slot * TTT_MAX_MOVES * ((double)cfg->mcts_simulations + 2.0);
@@ -886,7 +895,7 @@ nz_status nz_engine_play_next(nz_engine* e, uint64_t base_seed, int32_t have_nex
 nz_status nz_engine_phase_stamps(nz_engine* e, int32_t enable, double* out4_host) {
   if (!e) return NZ_ERR_ARG;
   if (out4_host) {
-    const int blocks = selfplay_blocks(e->n_slots);
+    const int blocks = selfplay_blocks(e->n_slots, e->tp.slots_per_wg);
     std::vector<unsigned long long> h((size_t)blocks * 6);
     NZ_HIP(e, hipSetDevice(e->device));
     NZ_HIP(e, hipDeviceSynchronize());

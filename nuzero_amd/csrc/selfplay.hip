@@ -173,11 +173,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     for (int i = threadIdx.x; i < LDS_TAB && i < p.tab_len; i += NET_THREADS) tab[i] = make_double2(p.sqrt_tab[i], p.bias_tab[i]);
     const int tid = threadIdx.x, slot = tree_slot(tid), sub = tid & (LANES_PER_GAME - 1);
     if (tree_lane(tid)) {
-      const int gslot = blockIdx.x * POS + slot;
+      const int gslot = blockIdx.x * p.slots_per_wg + slot;
       RootCache rc0;
       root_cache_load(rc0, arena_of(p, gslot < p.n_slots ? gslot : 0), 0, sub);
       RowState st0;
-      st0.alive = gslot < p.n_slots && gslot < p.n_games;
+      st0.alive = slot < p.slots_per_wg && gslot < p.n_slots && gslot < p.n_games;
       st0.g = gslot;                                     // game being played in this slot
       st0.sims_left = p.sims;
       park(st0, rc0, park_row, park_lane, slot, sub, tree_index(tid));
@@ -196,9 +196,9 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     const int tid = opaque(threadIdx.x);
     const int slot = tree_slot(tid);                     // game slot in the tile = network row
     const int sub = tid & (LANES_PER_GAME - 1);
-    const int gslot = blockIdx.x * POS + slot;           // global slot = tree arena
     const SelfplayArgs& ka = kernel_args();
     const TreeParams& p = ka.p;
+    const int gslot = blockIdx.x * p.slots_per_wg + slot;   // global slot = tree arena (rows past slots_per_wg: never alive)
     const double* const noise = ka.noise;
     const double* const uniforms = ka.uniforms;
     const int tab_n = p.tab_len < LDS_TAB ? p.tab_len : LDS_TAB;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
   const TreeParams& p = ea.p;
   unsigned long long* const stamps = ea.stamps;
   const int tid = opaque(threadIdx.x), slot = tree_slot(tid), sub = tid & (LANES_PER_GAME - 1);   // (not the prologue's copies)
-  const int gslot = blockIdx.x * POS + slot;
+  const int gslot = blockIdx.x * p.slots_per_wg + slot;
   if constexpr (STAMPS) {
     if (tid == 0) {
       stamps[blockIdx.x * 4 + 0] = n_cycles;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
     }
   }
 
-  if (tree_lane(tid) && gslot < p.n_slots && sub == 0) {
+  if (tree_lane(tid) && slot < p.slots_per_wg && gslot < p.n_slots && sub == 0) {
     p.alive[gslot] = 0;
     p.pending[gslot] = -1;
     p.n_root_children[gslot] = 0;
@@ -411,11 +411,11 @@ __global__ __launch_bounds__(NET_THREADS) void selfplay_kernel(SelfplayArgs) {
 
 }  // namespace
 
-int selfplay_blocks(int n_slots) { return (n_slots + POS - 1) / POS; }
+int selfplay_blocks(int n_slots, int slots_per_wg) { return (n_slots + slots_per_wg - 1) / slots_per_wg; }
 
 void launch_selfplay(const TreeParams& p, const NetProgram* prog_dev, int n_layers, const float* weights,
                      const double* noise, const double* uniforms, unsigned long long* stamps, hipStream_t s) {
-  const int blocks = selfplay_blocks(p.n_slots);
+  const int blocks = selfplay_blocks(p.n_slots, p.slots_per_wg);
   (void)n_layers;
   const SelfplayArgs a{p, prog_dev, weights, noise, uniforms, stamps};
   if (stamps != nullptr) hipLaunchKernelGGL(selfplay_kernel<true>, dim3(blocks), dim3(NET_THREADS), 0, s, a);
