@@ -345,8 +345,6 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
   p.softmax_moves = cfg->number_of_softmax_moves;
   p.eps_softmax = cfg->epsilon_softmax_exploration;
   p.eps_random = cfg->epsilon_random_exploration;
-  p.sims_per_cycle = 16;
-  if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
   {   // a workgroup's 16 network rows are filled only when there are 16 slots for every CU: fewer slots are spread over the
       // chip (1024 slots: 4 to each of 256 workgroups instead of 16 to each of 64 -- a pass costs the same matrix
       // instructions however many of its columns hold a leaf, and a tree phase waits for the slowest of fewer rows)
@@ -356,6 +354,11 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
     p.slots_per_wg = std::min(16, std::max(1, (n_slots + n_cu - 1) / n_cu));
     if (const char* v = getenv("NZ_SLOTS_PER_WG")) p.slots_per_wg = std::min(16, std::max(1, atoi(v)));   // tuning experiments
   }
+  // a row runs at most this many simulations between two network passes (results do not depend on it): 16 rows wait for
+  // the slowest, four or fewer can let it run on (1024 slots x 100 simulations on one box: 28.8 k games/s with 6, 30.1 k
+  // with 10, 30.8 k with 16, 31.4 k with 32 and 64; 4096 slots: 8 / 12 / 16 / 24 -> 105.7 / 106.8 / 106.0 / 105.1 k)
+  p.sims_per_cycle = p.slots_per_wg <= 4 ? 32 : 16;
+  if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
   {   // every cycle finishes at least one simulation or one move of every live row of the workgroup
     const double games_per_slot = std::ceil((double)p.n_games / (double)p.n_slots) + 2.0;
     const double bound = 16.0 * games_per_slot * TTT_MAX_MOVES * ((double)cfg->mcts_simulations + 2.0);
