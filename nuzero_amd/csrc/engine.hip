@@ -354,10 +354,10 @@ nz_status nz_engine_create_ex(nz_engine** out, const nz_search_cfg* cfg, const n
     p.slots_per_wg = std::min(16, std::max(1, (n_slots + n_cu - 1) / n_cu));
     if (const char* v = getenv("NZ_SLOTS_PER_WG")) p.slots_per_wg = std::min(16, std::max(1, atoi(v)));   // tuning experiments
   }
-  // a row runs at most this many simulations between two network passes (results do not depend on it): 16 rows wait for
-  // the slowest, four or fewer can let it run on (1024 slots x 100 simulations on one box: 28.8 k games/s with 6, 30.1 k
-  // with 10, 30.8 k with 16, 31.4 k with 32 and 64; 4096 slots: 8 / 12 / 16 / 24 -> 105.7 / 106.8 / 106.0 / 105.1 k)
-  p.sims_per_cycle = p.slots_per_wg <= 4 ? 32 : 16;
+  // a row runs at most this many simulations between two network passes (results do not depend on it).  With four slots to
+  // a workgroup more helps at 100 simulations a move (1024 slots, one box: 6 / 10 / 16 / 32 -> 28.8 / 30.1 / 30.8 / 31.4 k
+  // games/s) and hurts at configs[2]'s 400 (12 / 16 / 24 / 32 -> 8.76 / 8.68 / 8.52 / 8.52 k): 16 everywhere
+  p.sims_per_cycle = 16;
   if (const char* v = getenv("NZ_SIMS_PER_CYCLE")) p.sims_per_cycle = std::max(1, atoi(v));   // tuning experiments
   {   // every cycle finishes at least one simulation or one move of every live row of the workgroup
     const double games_per_slot = std::ceil((double)p.n_games / (double)p.n_slots) + 2.0;
